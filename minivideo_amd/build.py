@@ -1,0 +1,81 @@
+"""Build recipe for the native parts (run by __graft_entry__.build()).
+
+  libminivideo.so        product: host front end (C++) + HIP kernels, gfx950 only
+  liboracle_recon.so     checker (oracle/, plain C) -- test infrastructure
+  libmvgen.so            synthetic-stream generator -- test/bench infrastructure
+
+Everything is built in-tree so the shared objects travel with the repository
+snapshot to the GPU box.
+"""
+import glob
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "minivideo_amd")
+CSRC = os.path.join(PKG, "csrc")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+LIB = os.path.join(PKG, "libminivideo.so")
+GEN = os.path.join(PKG, "libmvgen.so")
+ORACLE = os.path.join(ROOT, "oracle", "liboracle_recon.so")
+
+
+def _newer(target, sources):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in sources)
+
+
+def _run(cmd):
+    print("+", " ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+
+
+def build_product(force=False):
+    hip_src = sorted(glob.glob(os.path.join(CSRC, "hip", "*.hip")))
+    host_src = sorted(glob.glob(os.path.join(CSRC, "host", "*.cpp")))
+    hdrs = (glob.glob(os.path.join(CSRC, "*", "*.h")) + glob.glob(os.path.join(CSRC, "*", "*.hpp"))
+            + glob.glob(os.path.join(CSRC, "*", "*.inc")) + glob.glob(os.path.join(ROOT, "include", "*.h")))
+    if not force and not _newer(LIB, hip_src + host_src + hdrs):
+        return LIB
+    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden",
+           "-pthread", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(CSRC, "hip"),
+           "-I" + os.path.join(CSRC, "host"), "-o", LIB]
+    cmd += hip_src
+    for s in host_src:
+        cmd += ["-x", "c++", s]
+    _run(cmd)
+    return LIB
+
+
+def build_generator(force=False):
+    src = sorted(glob.glob(os.path.join(CSRC, "gen", "*.cpp")))
+    if not src:
+        return None
+    hdrs = glob.glob(os.path.join(CSRC, "*", "*.h")) + glob.glob(os.path.join(CSRC, "*", "*.inc"))
+    if not force and not _newer(GEN, src + hdrs):
+        return GEN
+    _run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden",
+          "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(CSRC, "host"), "-o", GEN] + src)
+    return GEN
+
+
+def build_oracle(force=False):
+    src = [os.path.join(ROOT, "oracle", "recon_ref.c"), os.path.join(ROOT, "include", "minivideo_hotpath.h")]
+    if not force and not _newer(ORACLE, src):
+        return ORACLE
+    _run(["make", "-C", os.path.join(ROOT, "oracle"), "-B", "liboracle_recon.so"])
+    return ORACLE
+
+
+def build_all(force=False):
+    build_product(force)
+    build_generator(force)
+    build_oracle(force)
+
+
+if __name__ == "__main__":
+    build_all(force="--force" in sys.argv)

@@ -1,0 +1,291 @@
+// hotpath_abi.hip -- C-ABI (include/minivideo_hotpath.h) over the HIP kernels.
+// There is deliberately NO CPU fallback here: without a usable HIP device every
+// reconstruction entry point fails with MVHP_FAILURE and a message.
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "minivideo_hotpath.h"
+#include "recon_kernels.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+void set_err(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    fprintf(stderr, "[minivideo-hip] %s\n", g_err);
+}
+
+#define HIP_TRY(expr)                                                                  \
+    do {                                                                               \
+        hipError_t e_ = (expr);                                                        \
+        if (e_ != hipSuccess) {                                                        \
+            set_err("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return MVHP_FAILURE;                                                       \
+        }                                                                              \
+    } while (0)
+
+bool params_ok(const mvhp_stream_params_t *p)
+{
+    if (!p) return false;
+    if (p->width_mbs == 0 || p->height_mbs == 0) return false;
+    if (p->width_mbs > 1024 || p->height_mbs > 1024) return false; // LDS line buffer: 32 B per MB column
+    if (p->chroma_qp_index_offset < -12 || p->chroma_qp_index_offset > 12) return false;
+    if (p->second_chroma_qp_index_offset < -12 || p->second_chroma_qp_index_offset > 12) return false;
+    return true;
+}
+
+} // namespace
+
+struct mvhp_ctx {
+    int          device;
+    hipStream_t  stream;
+    uint32_t    *d_err;
+    int          waves;       // 0 = auto
+    int          n_cus;
+    size_t       max_lds;
+    // staging for the host convenience path
+    void        *d_packed;
+    size_t       d_packed_bytes;
+    uint8_t     *d_yuv;
+    size_t       d_yuv_bytes;
+    uint8_t     *d_rgb;
+    size_t       d_rgb_bytes;
+};
+
+extern "C" {
+
+MVHP_EXPORT const char *mvhp_last_error(void) { return g_err; }
+
+MVHP_EXPORT size_t mvhp_packed_frame_bytes(const mvhp_stream_params_t *p)
+{
+    return p ? (size_t)p->width_mbs * p->height_mbs * MVHP_MB_BYTES : 0;
+}
+MVHP_EXPORT size_t mvhp_yuv_frame_bytes(const mvhp_stream_params_t *p)
+{
+    return p ? (size_t)p->width_mbs * p->height_mbs * 384 : 0;
+}
+MVHP_EXPORT size_t mvhp_rgb_frame_bytes(const mvhp_stream_params_t *p)
+{
+    return p ? (size_t)p->width_mbs * p->height_mbs * 768 : 0;
+}
+
+MVHP_EXPORT int mvhp_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+MVHP_EXPORT int mvhp_create(int device, mvhp_ctx_t **out)
+{
+    if (!out) return MVHP_FAILURE;
+    *out = nullptr;
+    int n = mvhp_device_count();
+    if (n <= 0) {
+        set_err("no HIP device available: the reconstruction path has no CPU fallback");
+        return MVHP_FAILURE;
+    }
+    if (device < 0 || device >= n) {
+        set_err("device %d out of range (0..%d)", device, n - 1);
+        return MVHP_FAILURE;
+    }
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    mvhp_ctx *c = new mvhp_ctx();
+    memset(c, 0, sizeof(*c));
+    c->device = device;
+    c->n_cus = prop.multiProcessorCount;
+    c->max_lds = prop.maxSharedMemoryPerMultiProcessor ? prop.maxSharedMemoryPerMultiProcessor : 65536;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipMalloc(&c->d_err, sizeof(uint32_t)) != hipSuccess ||
+        hipMemset(c->d_err, 0, sizeof(uint32_t)) != hipSuccess) {
+        set_err("context allocation failed on device %d", device);
+        delete c;
+        return MVHP_FAILURE;
+    }
+    *out = c;
+    return MVHP_SUCCESS;
+}
+
+MVHP_EXPORT void mvhp_destroy(mvhp_ctx_t *c)
+{
+    if (!c) return;
+    hipSetDevice(c->device);
+    hipStreamSynchronize(c->stream);
+    if (c->d_packed) hipFree(c->d_packed);
+    if (c->d_yuv) hipFree(c->d_yuv);
+    if (c->d_rgb) hipFree(c->d_rgb);
+    if (c->d_err) hipFree(c->d_err);
+    hipStreamDestroy(c->stream);
+    delete c;
+}
+
+MVHP_EXPORT int mvhp_set_waves_per_picture(mvhp_ctx_t *c, int waves)
+{
+    if (!c || !(waves == 0 || waves == 4 || waves == 8 || waves == 16)) return MVHP_FAILURE;
+    c->waves = waves;
+    return MVHP_SUCCESS;
+}
+
+static int pick_waves(const mvhp_ctx *c, const mvhp_stream_params_t *p, int n_frames)
+{
+    int nw = c->waves;
+    (void)n_frames;
+    if (nw == 0) nw = 16; // speed only; see DESIGN.md "waves per picture"
+    while (nw > 4 && (nw / 2) >= (int)p->height_mbs) nw /= 2;
+    while (nw > 4 && mvhp::recon_lds_bytes((int)p->width_mbs, nw) > c->max_lds) nw /= 2;
+    return nw;
+}
+
+static int launch_all(mvhp_ctx *c, const mvhp_stream_params_t *p, const void *d_packed, int n_frames,
+                      uint8_t *d_yuv, uint8_t *d_rgb, hipStream_t st, bool recon, bool color)
+{
+    if (recon) {
+        mvhp::ReconArgs a;
+        a.packed = (const uint8_t *)d_packed;
+        a.yuv = d_yuv;
+        a.err = c->d_err;
+        a.width_mbs = (int)p->width_mbs;
+        a.height_mbs = (int)p->height_mbs;
+        a.cqp_off_cb = p->chroma_qp_index_offset;
+        a.cqp_off_cr = p->second_chroma_qp_index_offset;
+        const int nw = pick_waves(c, p, n_frames);
+        if (mvhp::recon_lds_bytes(a.width_mbs, nw) > c->max_lds) {
+            set_err("picture too wide for the LDS line buffer (%u macroblocks)", p->width_mbs);
+            return MVHP_UNSUPPORTED;
+        }
+        HIP_TRY(mvhp::launch_recon(a, n_frames, nw, st));
+    }
+    if (color && d_rgb) {
+        mvhp::ColorArgs ca;
+        ca.yuv = d_yuv;
+        ca.rgb = d_rgb;
+        ca.width_mbs = (int)p->width_mbs;
+        ca.height_mbs = (int)p->height_mbs;
+        ca.n_frames = n_frames;
+        HIP_TRY(mvhp::launch_color(ca, st));
+    }
+    return MVHP_SUCCESS;
+}
+
+MVHP_EXPORT int mvhp_recon_batch_dev(mvhp_ctx_t *c, const mvhp_stream_params_t *p, const void *d_packed,
+                                     int n_frames, uint8_t *d_yuv, uint8_t *d_rgb, void *stream)
+{
+    if (!c || !params_ok(p) || !d_packed || !d_yuv || n_frames <= 0) {
+        set_err("mvhp_recon_batch_dev: invalid argument");
+        return MVHP_FAILURE;
+    }
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+    return launch_all(c, p, d_packed, n_frames, d_yuv, d_rgb, st, true, true);
+}
+
+static int ensure(void **ptr, size_t *have, size_t need)
+{
+    if (*have >= need) return MVHP_SUCCESS;
+    if (*ptr) hipFree(*ptr);
+    *ptr = nullptr;
+    *have = 0;
+    HIP_TRY(hipMalloc(ptr, need));
+    *have = need;
+    return MVHP_SUCCESS;
+}
+
+MVHP_EXPORT int mvhp_recon_batch_host(mvhp_ctx_t *c, const mvhp_stream_params_t *p, const void *h_packed,
+                                      int n_frames, uint8_t *h_yuv, uint8_t *h_rgb)
+{
+    if (!c || !params_ok(p) || !h_packed || !h_yuv || n_frames <= 0) {
+        set_err("mvhp_recon_batch_host: invalid argument");
+        return MVHP_FAILURE;
+    }
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t pb = mvhp_packed_frame_bytes(p) * n_frames;
+    const size_t yb = mvhp_yuv_frame_bytes(p) * n_frames;
+    const size_t rb = mvhp_rgb_frame_bytes(p) * n_frames;
+    if (ensure(&c->d_packed, &c->d_packed_bytes, pb) != MVHP_SUCCESS) return MVHP_FAILURE;
+    if (ensure((void **)&c->d_yuv, &c->d_yuv_bytes, yb) != MVHP_SUCCESS) return MVHP_FAILURE;
+    if (h_rgb && ensure((void **)&c->d_rgb, &c->d_rgb_bytes, rb) != MVHP_SUCCESS) return MVHP_FAILURE;
+    HIP_TRY(hipMemsetAsync(c->d_err, 0, sizeof(uint32_t), c->stream));
+    HIP_TRY(hipMemcpyAsync(c->d_packed, h_packed, pb, hipMemcpyHostToDevice, c->stream));
+    int rc = launch_all(c, p, c->d_packed, n_frames, c->d_yuv, h_rgb ? c->d_rgb : nullptr, c->stream, true, true);
+    if (rc != MVHP_SUCCESS) return rc;
+    HIP_TRY(hipMemcpyAsync(h_yuv, c->d_yuv, yb, hipMemcpyDeviceToHost, c->stream));
+    if (h_rgb) HIP_TRY(hipMemcpyAsync(h_rgb, c->d_rgb, rb, hipMemcpyDeviceToHost, c->stream));
+    uint32_t err = 0;
+    HIP_TRY(hipMemcpyAsync(&err, c->d_err, sizeof(err), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (err) {
+        set_err("reconstruction kernel reported error word 0x%x (row dependency wait timed out)", err);
+        return MVHP_FAILURE;
+    }
+    return MVHP_SUCCESS;
+}
+
+MVHP_EXPORT int mvhp_sync_check(mvhp_ctx_t *c, void *stream)
+{
+    if (!c) return MVHP_FAILURE;
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+    uint32_t err = 0;
+    HIP_TRY(hipMemcpyAsync(&err, c->d_err, sizeof(err), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (err) {
+        set_err("reconstruction kernel reported error word 0x%x (row dependency wait timed out)", err);
+        hipMemset(c->d_err, 0, sizeof(uint32_t));
+        return MVHP_FAILURE;
+    }
+    return MVHP_SUCCESS;
+}
+
+MVHP_EXPORT int mvhp_time_recon(mvhp_ctx_t *c, const mvhp_stream_params_t *p, const void *d_packed, int n_frames,
+                                uint8_t *d_yuv, uint8_t *d_rgb, void *stream, int iters, float *ms_recon,
+                                float *ms_color)
+{
+    if (!c || !params_ok(p) || !d_packed || !d_yuv || n_frames <= 0 || iters <= 0) {
+        set_err("mvhp_time_recon: invalid argument");
+        return MVHP_FAILURE;
+    }
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+    hipEvent_t e0, e1, e2;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    HIP_TRY(hipEventCreate(&e2));
+    float tr = 0.f, tc = 0.f;
+    int rc = MVHP_SUCCESS;
+    for (int i = 0; i < iters && rc == MVHP_SUCCESS; i++) {
+        HIP_TRY(hipEventRecord(e0, st));
+        rc = launch_all(c, p, d_packed, n_frames, d_yuv, d_rgb, st, true, false);
+        HIP_TRY(hipEventRecord(e1, st));
+        if (rc == MVHP_SUCCESS && d_rgb) rc = launch_all(c, p, d_packed, n_frames, d_yuv, d_rgb, st, false, true);
+        HIP_TRY(hipEventRecord(e2, st));
+        HIP_TRY(hipEventSynchronize(e2));
+        float a = 0.f, b = 0.f;
+        HIP_TRY(hipEventElapsedTime(&a, e0, e1));
+        HIP_TRY(hipEventElapsedTime(&b, e1, e2));
+        tr += a;
+        tc += b;
+    }
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    hipEventDestroy(e2);
+    if (ms_recon) *ms_recon = tr / iters;
+    if (ms_color) *ms_color = d_rgb ? tc / iters : 0.f;
+    uint32_t err = 0;
+    HIP_TRY(hipMemcpy(&err, c->d_err, sizeof(err), hipMemcpyDeviceToHost));
+    if (err) {
+        set_err("reconstruction kernel reported error word 0x%x", err);
+        return MVHP_FAILURE;
+    }
+    return rc;
+}
+
+} // extern "C"

@@ -1,0 +1,27 @@
+// recon_kernels.h -- launch interface between the C-ABI layer and the kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace mvhp {
+
+struct ReconArgs {
+    const uint8_t *packed;   // n_frames * W*H * 800 B packed macroblock records
+    uint8_t       *yuv;      // n_frames * W*H * 384 B planar Y|Cb|Cr
+    uint32_t      *err;      // device word: bit0 = dependency wait timed out
+    int            width_mbs, height_mbs;
+    int            cqp_off_cb, cqp_off_cr;
+};
+
+struct ColorArgs {
+    const uint8_t *yuv;
+    uint8_t       *rgb;
+    int            width_mbs, height_mbs, n_frames;
+};
+
+size_t     recon_lds_bytes(int width_mbs, int nw);
+hipError_t launch_recon(const ReconArgs &a, int n_frames, int nw, hipStream_t stream);
+hipError_t launch_color(const ColorArgs &a, hipStream_t stream);
+
+} // namespace mvhp

@@ -1,0 +1,798 @@
+// recon_kernels.hip -- hand-written CDNA4 (gfx950) kernels for the H.264 intra
+// reconstruction hot path.  Integer stencil work: no MFMA, HBM/LDS-latency bound.
+//
+//   recon_rows_kernel<NW>   replaces intra_prediction_process()
+//                           (decoder/h264/h264_intra_prediction.c:112-145) for a
+//                           whole picture: all prediction modes, dequantisation,
+//                           4x4/8x8 IDCT, DC transforms, residual add + clip and
+//                           the planar gather of export.c:65-188.
+//   ycbcr_to_rgb_kernel     replaces mb_to_rgb() (export_utils.c:209-324).
+//
+// Mapping: one workgroup per picture, NW wavefronts (64 lanes) per workgroup,
+// one wavefront per macroblock row (wave w owns rows w, w+NW, ...).  Row r may
+// reconstruct macroblock x once row r-1 has published x+2 (left/up/up-left/
+// up-right dependencies); publication is a per-wave counter in LDS, so the whole
+// dependency protocol stays inside one CU (no agent-scope fences).  The bottom
+// sample row of every macroblock row lives in ONE LDS line buffer per picture
+// (each row overwrites column x after it has consumed it), the left column and
+// the macroblock being built live in a per-wave LDS tile.  Residuals
+// (dequantised + inverse-transformed coefficients) are staged through LDS as
+// int16; raw coefficients go global -> registers of the lane that owns the 4x4
+// block (800 contiguous bytes per macroblock, read exactly once).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "minivideo_hotpath.h"
+#include "recon_kernels.h"
+
+namespace mvhp {
+
+// ---------------------------------------------------------------------------
+// LDS layout
+// ---------------------------------------------------------------------------
+struct __attribute__((aligned(16))) WaveLds {
+    int16_t res[384];      // residuals, MB raster: luma y*16+x | 256+Cb y*8+x | 320+Cr
+    uint8_t T[17 * 32 + 16]; // luma tile: row 0 = top neighbours; byte 15 = left/corner, 16..31 samples;
+                           // row 0 bytes 32..39 = up-right neighbours
+    uint8_t TC[2][9 * 16]; // chroma tiles: row 0 = top; byte 7 = left/corner, 8..15 samples
+    uint8_t Lcol[16];      // compact left neighbour column (luma)
+    uint8_t LcolC[2][8];   // compact left neighbour columns (Cb, Cr)
+    uint8_t E8[32];        // filtered Intra8x8 edge: [0..1]=rep left7, [2+j]=left[7-j], [10]=corner, [11+i]=top[i], [27]=rep
+    int32_t scr[256];      // 8x8 transpose scratch / DC exchange
+};
+
+struct __attribute__((aligned(16))) BlockLds {
+    int     progress[16];  // macroblocks completed by wave w (monotonic over its rows)
+    int     abort_flag;
+    int     pad[3];
+    int     ls4[18];       // LevelScale4x4 classes, 16*normAdjust (h264.c:427-435)
+    int     ls8[36];       // LevelScale8x8 classes (h264.c:438-446)
+    uint8_t cls8[64];      // 8x8 position -> class
+    uint8_t tab4[9 * 16];  // Intra4x4 mode tables: k | type<<5
+    uint8_t tab8[9 * 64];  // Intra8x8 mode tables
+};
+
+__device__ static const int c_v4x4[18] = {10, 16, 13, 11, 18, 14, 13, 20, 16, 14, 23, 18, 16, 25, 20, 18, 29, 23};
+__device__ static const int c_v8x8[36] = {20, 18, 32, 19, 25, 24, 22, 19, 35, 21, 28, 26, 26, 23, 42, 24, 33, 31,
+                                          28, 25, 45, 26, 35, 33, 32, 28, 51, 30, 40, 38, 36, 32, 58, 34, 46, 43};
+__device__ static const uint8_t c_qpc[22] = {29, 30, 31, 32, 32, 33, 34, 34, 35, 35, 36,
+                                             36, 37, 37, 37, 38, 38, 38, 39, 39, 39, 39};
+
+#define WAVE_SYNC()                                              \
+    do {                                                         \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   \
+        __builtin_amdgcn_wave_barrier();                         \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   \
+    } while (0)
+
+__device__ __forceinline__ int clip255(int v) { return min(max(v, 0), 255); }
+
+// Prediction table entry for an n x n block (n = 4 or 8), unified edge array
+// EE: EE[0..1] = left[n-1] replicated, EE[2+j] = left[n-1-j], EE[cor] = p[-1,-1],
+// EE[top0+i] = top[i] (i < 2n), EE[top0+2n] = top[2n-1] replicated.
+// type 0: EE[k]; 1: (EE[k]+EE[k+1]+1)>>1; 2: (EE[k]+2EE[k+1]+EE[k+2]+2)>>2.
+// Restates the nine mode functions h264_intra_prediction.c:496-960 (4x4) and
+// :1366-1793 (8x8).
+__device__ int mode_entry(int n, int mode, int x, int y)
+{
+    const int top0 = (n == 4) ? 7 : 11, cor = top0 - 1, left0 = top0 - 2;
+    int k = 0, t = 0;
+    switch (mode) {
+    case 0: k = top0 + x; t = 0; break;
+    case 1: k = left0 - y; t = 0; break;
+    case 3: k = top0 + x + y; t = 2; break;
+    case 4: k = left0 + x - y; t = 2; break;
+    case 5: {
+        int z = 2 * x - y;
+        if (z >= 0) { if ((z & 1) == 0) { k = cor + x - (y >> 1); t = 1; } else { k = left0 + x - (y >> 1); t = 2; } }
+        else if (z == -1) { k = left0; t = 2; }
+        else { k = cor - y + 2 * x; t = 2; }
+        break;
+    }
+    case 6: {
+        int z = 2 * y - x;
+        if (z >= 0) { k = left0 - y + (x >> 1); t = ((z & 1) == 0) ? 1 : 2; }
+        else if (z == -1) { k = left0; t = 2; }
+        else { k = left0 - 1 + x - 2 * y; t = 2; }
+        break;
+    }
+    case 7: k = top0 + x + (y >> 1); t = (y & 1) ? 2 : 1; break;
+    case 8: {
+        int s = y + (x >> 1), z = x + 2 * y;
+        if ((z & 1) == 0) { k = left0 - 1 - s; t = 1; } else { k = left0 - 2 - s; t = 2; }
+        if (k < 0) k = 0;
+        break;
+    }
+    default: break;
+    }
+    return k | (t << 5);
+}
+
+// ---------------------------------------------------------------------------
+// residual arithmetic (h264_transform.c)
+// ---------------------------------------------------------------------------
+
+// idct4x4, h264_transform.c:1145-1191, in place on d[row*4+col]
+__device__ __forceinline__ void idct4x4(int d[16])
+{
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        int e0 = d[i * 4 + 0] + d[i * 4 + 2];
+        int e1 = d[i * 4 + 0] - d[i * 4 + 2];
+        int e2 = (d[i * 4 + 1] >> 1) - d[i * 4 + 3];
+        int e3 = d[i * 4 + 1] + (d[i * 4 + 3] >> 1);
+        d[i * 4 + 0] = e0 + e3;
+        d[i * 4 + 1] = e1 + e2;
+        d[i * 4 + 2] = e1 - e2;
+        d[i * 4 + 3] = e0 - e3;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        int g0 = d[0 + j] + d[8 + j];
+        int g1 = d[0 + j] - d[8 + j];
+        int g2 = (d[4 + j] >> 1) - d[12 + j];
+        int g3 = d[4 + j] + (d[12 + j] >> 1);
+        d[0 + j]  = (g0 + g3 + 32) >> 6;
+        d[4 + j]  = (g1 + g2 + 32) >> 6;
+        d[8 + j]  = (g1 - g2 + 32) >> 6;
+        d[12 + j] = (g0 - g3 + 32) >> 6;
+    }
+}
+
+// 8-point butterfly of idct8x8 (h264_transform.c:1308-1342 / :1344-1378), in place.
+__device__ __forceinline__ void idct8_1d(int d[8])
+{
+    int e0 = d[0] + d[4];
+    int e1 = -d[3] + d[5] - d[7] - (d[7] >> 1);
+    int e2 = d[0] - d[4];
+    int e3 = d[1] + d[7] - d[3] - (d[3] >> 1);
+    int e4 = (d[2] >> 1) - d[6];
+    int e5 = -d[1] + d[7] + d[5] + (d[5] >> 1);
+    int e6 = d[2] + (d[6] >> 1);
+    int e7 = d[3] + d[5] + d[1] + (d[1] >> 1);
+    int f0 = e0 + e6;
+    int f1 = e1 + (e7 >> 2);
+    int f2 = e2 + e4;
+    int f3 = e3 + (e5 >> 2);
+    int f4 = e2 - e4;
+    int f5 = (e3 >> 2) - e5;
+    int f6 = e0 - e6;
+    int f7 = e7 - (e1 >> 2);
+    d[0] = f0 + f7;
+    d[1] = f2 + f5;
+    d[2] = f4 + f3;
+    d[3] = f6 + f1;
+    d[4] = f6 - f1;
+    d[5] = f4 - f3;
+    d[6] = f2 - f5;
+    d[7] = f0 - f7;
+}
+
+// sign of idct_dccoeff_4x4[i][k] (h264_transform.c:62-68): rows ++++, ++--, +--+, +-+-
+__device__ __forceinline__ bool hneg(int i, int k)
+{
+    return (i == 1 && k >= 2) || (i == 2 && (k == 1 || k == 2)) || (i == 3 && (k & 1));
+}
+
+__device__ __forceinline__ int sat9(int r) { return min(max(r, -256), 255); }
+
+// Residual stage for one macroblock: fills W.res. Lanes: 4x4 path lane b < 24
+// owns block b (0-15 luma, 16-19 Cb, 20-23 Cr); 8x8 path lanes 0-31 own one
+// row, then one column, of a luma 8x8 block.
+__device__ __forceinline__ void residual_stage(WaveLds &W, const BlockLds &B, const uint8_t *mbp, int lane,
+                                               int kind, int qpy, int qpc_cb, int qpc_cr)
+{
+    const int16_t *coef = reinterpret_cast<const int16_t *>(mbp + MVHP_MB_HEADER_BYTES);
+
+    // ---- luma 8x8 (transform_8x8_residual, h264_transform.c:1205-1383) ----
+    if (kind == MVHP_KIND_I8x8) {
+        const int m = qpy % 6, s = qpy / 6;
+        if (lane < 32) {
+            const int blk = lane >> 3, row = lane & 7;
+            const int4 raw = *reinterpret_cast<const int4 *>(coef + blk * 64 + row * 8);
+            int d[8];
+            d[0] = (int16_t)(raw.x & 0xffff); d[1] = raw.x >> 16;
+            d[2] = (int16_t)(raw.y & 0xffff); d[3] = raw.y >> 16;
+            d[4] = (int16_t)(raw.z & 0xffff); d[5] = raw.z >> 16;
+            d[6] = (int16_t)(raw.w & 0xffff); d[7] = raw.w >> 16;
+            if (qpy > 35) {
+#pragma unroll
+                for (int j = 0; j < 8; j++)
+                    d[j] = (int)((unsigned)(d[j] * B.ls8[m * 6 + B.cls8[row * 8 + j]]) << ((s - 6) & 31));
+            } else {
+                const int rnd = 1 << ((5 - s) & 31), sh = (6 - s) & 31;
+#pragma unroll
+                for (int j = 0; j < 8; j++)
+                    d[j] = (d[j] * B.ls8[m * 6 + B.cls8[row * 8 + j]] + rnd) >> sh;
+            }
+            idct8_1d(d);
+#pragma unroll
+            for (int j = 0; j < 8; j++) W.scr[blk * 64 + row * 8 + j] = d[j];
+        }
+        WAVE_SYNC();
+        if (lane < 32) {
+            const int blk = lane >> 3, col = lane & 7;
+            int d[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) d[i] = W.scr[blk * 64 + i * 8 + col];
+            idct8_1d(d);
+            const int xO = (blk & 1) * 8, yO = (blk >> 1) * 8;
+#pragma unroll
+            for (int i = 0; i < 8; i++) W.res[(yO + i) * 16 + xO + col] = (int16_t)sat9((d[i] + 32) >> 6);
+        }
+        WAVE_SYNC();
+    }
+
+    // ---- 4x4 blocks (transform_4x4_residual, h264_transform.c:1049-1191) ----
+    const int first = (kind == MVHP_KIND_I8x8) ? 16 : 0;
+    const bool act = (lane >= first) && (lane < 24);
+    int d[16];
+    if (act) {
+        const int4 r0 = *reinterpret_cast<const int4 *>(coef + lane * 16);
+        const int4 r1 = *reinterpret_cast<const int4 *>(coef + lane * 16 + 8);
+        d[0] = (int16_t)(r0.x & 0xffff); d[1] = r0.x >> 16; d[2] = (int16_t)(r0.y & 0xffff); d[3] = r0.y >> 16;
+        d[4] = (int16_t)(r0.z & 0xffff); d[5] = r0.z >> 16; d[6] = (int16_t)(r0.w & 0xffff); d[7] = r0.w >> 16;
+        d[8] = (int16_t)(r1.x & 0xffff); d[9] = r1.x >> 16; d[10] = (int16_t)(r1.y & 0xffff); d[11] = r1.y >> 16;
+        d[12] = (int16_t)(r1.z & 0xffff); d[13] = r1.z >> 16; d[14] = (int16_t)(r1.w & 0xffff); d[15] = r1.w >> 16;
+        W.scr[lane] = d[0];
+    }
+    WAVE_SYNC();
+    if (act) {
+        const bool chroma = lane >= 16;
+        const int qP = chroma ? ((lane >= 20) ? qpc_cr : qpc_cb) : qpy;
+        const int m = qP % 6, s = qP / 6;
+        const int lsA = B.ls4[m * 3 + 0], lsB = B.ls4[m * 3 + 1], lsC = B.ls4[m * 3 + 2];
+        int dc = d[0];
+        const bool keep_dc = chroma || (kind == MVHP_KIND_I16x16);
+        if (chroma) {
+            // transform_2x2_chromadc, h264_transform.c:827-860, :924-936, :988-1005
+            const int base = (lane >= 20) ? 20 : 16, k = lane - base;
+            const int c0 = W.scr[base], c1 = W.scr[base + 1], c2 = W.scr[base + 2], c3 = W.scr[base + 3];
+            int f = (k == 0) ? (c0 + c1 + c2 + c3) : (k == 1) ? (c0 - c1 + c2 - c3)
+                  : (k == 2) ? (c0 + c1 - c2 - c3) : (c0 - c1 - c2 + c3);
+            dc = (int)((unsigned)(f * lsA) << s) >> 5;
+        } else if (kind == MVHP_KIND_I16x16) {
+            // transform_16x16_lumadc, h264_transform.c:756-812 (incl. the `qP > 36` test)
+            const int bi = ((lane >> 3) << 1) | ((lane >> 1) & 1);   // block row of luma4x4BlkIdx
+            const int bj = (((lane >> 2) & 1) << 1) | (lane & 1);    // block column
+            int f = 0;
+#pragma unroll
+            for (int b = 0; b < 16; b++) {
+                const int ri = ((b >> 3) << 1) | ((b >> 1) & 1), rj = (((b >> 2) & 1) << 1) | (b & 1);
+                const int v = W.scr[b];                       // c[ri][rj]
+                f += (hneg(bi, ri) != hneg(rj, bj)) ? -v : v; // H4[bi][ri] * c * H4[rj][bj]
+            }
+            if (qpy > 36) dc = (int)((unsigned)(f * lsA) << ((s - 6) & 31));
+            else dc = (int)((unsigned)(f * lsA) + (1u << ((5 - s) & 31))) >> ((6 - s) & 31);
+        }
+        // quant4x4, h264_transform.c:1100-1134
+        if (qP > 23) {
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const int r = i >> 2, c = i & 3;
+                const int ls = ((r & 1) == 0 && (c & 1) == 0) ? lsA : (((r & 1) && (c & 1)) ? lsB : lsC);
+                d[i] = (int)((unsigned)(d[i] * ls) << ((s - 4) & 31));
+            }
+        } else {
+            const int rnd = 1 << ((3 - s) & 31), sh = (4 - s) & 31;
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const int r = i >> 2, c = i & 3;
+                const int ls = ((r & 1) == 0 && (c & 1) == 0) ? lsA : (((r & 1) && (c & 1)) ? lsB : lsC);
+                d[i] = (d[i] * ls + rnd) >> sh;
+            }
+        }
+        if (keep_dc) d[0] = dc;
+        idct4x4(d);
+        int base, stride;
+        if (!chroma) {
+            const int xO = (((lane >> 2) & 1) << 3) | ((lane & 1) << 2);
+            const int yO = ((lane >> 3) << 3) | (((lane >> 1) & 1) << 2);
+            base = yO * 16 + xO; stride = 16;
+        } else {
+            const int k = lane & 3;
+            base = 256 + ((lane >= 20) ? 64 : 0) + (k >> 1) * 32 + (k & 1) * 4; stride = 8;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            int2 pk;
+            pk.x = (sat9(d[i * 4 + 0]) & 0xffff) | (sat9(d[i * 4 + 1]) << 16);
+            pk.y = (sat9(d[i * 4 + 2]) & 0xffff) | (sat9(d[i * 4 + 3]) << 16);
+            *reinterpret_cast<int2 *>(&W.res[base + i * stride]) = pk;
+        }
+    }
+    WAVE_SYNC();
+}
+
+// ---------------------------------------------------------------------------
+// prediction helpers
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ int sum4(uint32_t w) { return (int)__builtin_amdgcn_sad_u8(w, 0u, 0u); }
+
+// Intra 4x4 block: lanes 0..15 (x = lane&3, y = lane>>2).
+// h264_intra_prediction.c:315-483 + transform4x4_luma (h264_transform.c:121-156).
+__device__ __forceinline__ void predict_4x4(WaveLds &W, const BlockLds &B, int lane, int blk, int mode,
+                                            bool A, bool Bv, bool C, bool D, bool has_res)
+{
+    const int xO = (((blk >> 2) & 1) << 3) | ((blk & 1) << 2);
+    const int yO = ((blk >> 3) << 3) | (((blk >> 1) & 1) << 2);
+    const bool left = (xO > 0) || A;
+    const bool up = (yO > 0) || Bv;
+    const bool upleft = (xO > 0) ? ((yO > 0) || Bv) : ((yO > 0) ? A : D);
+    bool upright;
+    if (xO + 4 > 15) upright = (yO == 0) ? C : false;
+    else if (blk == 3 || blk == 11) upright = false;
+    else upright = (yO == 0) ? Bv : true;
+    if (lane < 16) {
+        const int x = lane & 3, y = lane >> 2;
+        const uint8_t *Trow = &W.T[yO * 32 + 16 + xO];        // p[0,-1] of this block
+        const uint8_t *Tcol = &W.T[(yO + 1) * 32 + 15 + xO];  // p[-1,0]
+        int pred = 0;
+        if (mode == 2) {
+            const int sumH = sum4(*reinterpret_cast<const uint32_t *>(Trow));
+            const int sumV = Tcol[0] + Tcol[32] + Tcol[64] + Tcol[96];
+            if (left && up) pred = (sumH + sumV + 4) >> 3;
+            else if (left) pred = (sumV + 2) >> 2;
+            else if (up) pred = (sumH + 2) >> 2;
+            else pred = 128;
+        } else {
+            bool ok;
+            switch (mode) {
+            case 0: case 3: case 7: ok = up; break;
+            case 1: case 8: ok = left; break;
+            default: ok = left && up && upleft; break; // 4, 5, 6
+            }
+            if (ok) {
+                const int e = B.tab4[mode * 16 + lane];
+                const int k = e & 31, t = e >> 5;
+                const int maxi = upright ? 7 : 3;
+                int v[3];
+#pragma unroll
+                for (int q = 0; q < 3; q++) {
+                    const int idx = k + q;
+                    int a;
+                    if (idx >= 6) a = (int)Trow[min(idx - 7, maxi)];
+                    else a = (int)Tcol[min(5 - idx, 3) * 32];
+                    v[q] = a;
+                }
+                pred = (t == 0) ? v[0] : (t == 1) ? ((v[0] + v[1] + 1) >> 1) : ((v[0] + 2 * v[1] + v[2] + 2) >> 2);
+            }
+        }
+        const int r = has_res ? (int)W.res[(yO + y) * 16 + xO + x] : 0;
+        W.T[(yO + y + 1) * 32 + 16 + xO + x] = (uint8_t)clip255(pred + r);
+    }
+    WAVE_SYNC();
+}
+
+// Intra 8x8 block: edge filtering by lanes 0..27, prediction by all 64 lanes.
+// h264_intra_prediction.c:1107-1353 + :1366-1793 + transform8x8_luma.
+__device__ __forceinline__ void predict_8x8(WaveLds &W, const BlockLds &B, int lane, int blk, int mode,
+                                            bool A, bool Bv, bool C, bool D, bool has_res)
+{
+    const int xO = (blk & 1) * 8, yO = (blk >> 1) * 8;
+    const bool left = (xO > 0) || A;
+    const bool up = (yO > 0) || Bv;
+    const bool upleft = (xO > 0) ? ((yO > 0) || Bv) : ((yO > 0) ? A : D);
+    const bool upright = (blk == 0) ? Bv : (blk == 1) ? C : (blk == 2);
+    const uint8_t *Trow = &W.T[yO * 32 + 16 + xO];
+    const uint8_t *Tcol = &W.T[(yO + 1) * 32 + 15 + xO];
+    if (lane < 28) {
+        // raw edge sample for EE8 index e: e<=9: left[9-e] (clamped), 10: corner, >=11: top[e-11]
+        const int e = min(max(lane, 2), 26);
+        const int maxi = upright ? 15 : 7;
+        int lo = e - 1, hi = e + 1;
+        if (e == 2 || (e == 11 && !upleft) || (e == 10 && !left)) lo = e;
+        if (e == 26 || (e == 9 && !upleft) || (e == 10 && !up)) hi = e;
+        int v[3];
+        const int idxs[3] = {lo, e, hi};
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+            const int idx = idxs[q];
+            int a;
+            if (idx >= 10) a = (int)Trow[min(idx - 11, maxi)];
+            else a = (int)Tcol[(9 - idx) * 32];
+            v[q] = a;
+        }
+        W.E8[lane] = (uint8_t)((v[0] + 2 * v[1] + v[2] + 2) >> 2);
+    }
+    WAVE_SYNC();
+    {
+        const int x = lane & 7, y = lane >> 3;
+        int pred = 0;
+        if (mode == 2) {
+            const uint32_t *E = reinterpret_cast<const uint32_t *>(W.E8);
+            const uint32_t w0 = E[0], w1 = E[1], w2 = E[2], w3 = E[3], w4 = E[4];
+            const int sumV = sum4(w0 & 0xffff0000u) + sum4(w1) + sum4(w2 & 0x0000ffffu);       // E8[2..9]
+            const int sumH = sum4(w2 & 0xff000000u) + sum4(w3) + sum4(w4 & 0x00ffffffu);       // E8[11..18]
+            if (left && up) pred = (sumH + sumV + 8) >> 4;
+            else if (left) pred = (sumV + 4) >> 3;
+            else if (up) pred = (sumH + 4) >> 3;
+            else pred = 128;
+        } else {
+            bool ok;
+            switch (mode) {
+            case 0: case 3: case 7: ok = up; break;
+            case 1: case 8: ok = left; break;
+            default: ok = left && up && upleft; break;
+            }
+            if (ok) {
+                const int e = B.tab8[mode * 64 + lane];
+                const int k = e & 31, t = e >> 5;
+                const int v0 = W.E8[k], v1 = W.E8[min(k + 1, 27)], v2 = W.E8[min(k + 2, 27)];
+                pred = (t == 0) ? v0 : (t == 1) ? ((v0 + v1 + 1) >> 1) : ((v0 + 2 * v1 + v2 + 2) >> 2);
+            }
+        }
+        const int r = has_res ? (int)W.res[(yO + y) * 16 + xO + x] : 0;
+        W.T[(yO + y + 1) * 32 + 16 + xO + x] = (uint8_t)clip255(pred + r);
+    }
+    WAVE_SYNC();
+}
+
+// Intra 16x16: 64 lanes x 4 samples. h264_intra_prediction.c:1809-2141 + transform16x16_luma.
+__device__ __forceinline__ void predict_16x16(WaveLds &W, int lane, int mode, bool A, bool Bv, bool has_res)
+{
+    const int y = lane >> 2, x0 = (lane & 3) * 4;
+    const bool left = A, up = Bv;
+    const uint4 topv = *reinterpret_cast<const uint4 *>(&W.T[16]);
+    const uint4 lefv = *reinterpret_cast<const uint4 *>(W.Lcol);
+    int p[4] = {0, 0, 0, 0};
+    if (mode == 0) {
+        if (up) {
+            const uint32_t w = (lane & 3) == 0 ? topv.x : (lane & 3) == 1 ? topv.y : (lane & 3) == 2 ? topv.z : topv.w;
+            p[0] = w & 255; p[1] = (w >> 8) & 255; p[2] = (w >> 16) & 255; p[3] = w >> 24;
+        }
+    } else if (mode == 1) {
+        if (left) { const int v = W.Lcol[y]; p[0] = p[1] = p[2] = p[3] = v; }
+    } else if (mode == 2) {
+        const int sumH = sum4(topv.x) + sum4(topv.y) + sum4(topv.z) + sum4(topv.w);
+        const int sumV = sum4(lefv.x) + sum4(lefv.y) + sum4(lefv.z) + sum4(lefv.w);
+        int v;
+        if (left && up) v = (sumH + sumV + 16) >> 5;
+        else if (left) v = (sumV + 8) >> 4;
+        else if (up) v = (sumH + 8) >> 4;
+        else v = 128;
+        p[0] = p[1] = p[2] = p[3] = v;
+    } else if (mode == 3) {
+        if (left && up) {
+            const int cor = W.T[15];
+            const uint32_t tw[4] = {topv.x, topv.y, topv.z, topv.w};
+            const uint32_t lw[4] = {lefv.x, lefv.y, lefv.z, lefv.w};
+            int H = 0, V = 0;
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const int hi = 8 + i, lo = 6 - i;
+                const int th = (tw[hi >> 2] >> ((hi & 3) * 8)) & 255;
+                const int lh = (lw[hi >> 2] >> ((hi & 3) * 8)) & 255;
+                const int tl = (lo < 0) ? cor : (int)((tw[lo >> 2] >> ((lo & 3) * 8)) & 255);
+                const int ll = (lo < 0) ? cor : (int)((lw[lo >> 2] >> ((lo & 3) * 8)) & 255);
+                H += (i + 1) * (th - tl);
+                V += (i + 1) * (lh - ll);
+            }
+            const int a = 16 * ((int)(lefv.w >> 24) + (int)(topv.w >> 24));
+            const int b = (5 * H + 32) >> 6;
+            const int c = (5 * V + 32) >> 6;
+#pragma unroll
+            for (int q = 0; q < 4; q++) p[q] = clip255((a + b * (x0 + q - 7) + c * (y - 7) + 16) >> 5);
+        }
+    }
+    if (has_res) {
+        const int2 rr = *reinterpret_cast<const int2 *>(&W.res[y * 16 + x0]);
+        p[0] += (int16_t)(rr.x & 0xffff); p[1] += rr.x >> 16;
+        p[2] += (int16_t)(rr.y & 0xffff); p[3] += rr.y >> 16;
+    }
+    const uint32_t out = (uint32_t)clip255(p[0]) | ((uint32_t)clip255(p[1]) << 8) |
+                         ((uint32_t)clip255(p[2]) << 16) | ((uint32_t)clip255(p[3]) << 24);
+    *reinterpret_cast<uint32_t *>(&W.T[(y + 1) * 32 + 16 + x0]) = out;
+    WAVE_SYNC();
+}
+
+// Chroma, both planes: lane -> plane = lane>>5, y = (lane&31)>>2, x0 = (lane&3)*2.
+// h264_intra_prediction.c:2157-2564 + transform4x4_chroma.
+__device__ __forceinline__ void predict_chroma(WaveLds &W, int lane, int mode, bool A, bool Bv, bool has_res)
+{
+    const int pl = lane >> 5, y = (lane & 31) >> 2, x0 = (lane & 3) * 2;
+    const bool left = A, up = Bv;
+    const uint8_t *TC = W.TC[pl];
+    const uint2 topv = *reinterpret_cast<const uint2 *>(&TC[8]);
+    const uint2 lefv = *reinterpret_cast<const uint2 *>(W.LcolC[pl]);
+    int p0 = 0, p1 = 0;
+    if (mode == 0) {
+        const int bx = x0 >> 2, by = y >> 2;
+        const int sH = sum4(bx ? topv.y : topv.x), sV = sum4(by ? lefv.y : lefv.x);
+        int v;
+        if (!left && !up) v = 128;
+        else if (bx == by) {
+            if (left && up) v = (sH + sV + 4) >> 3;
+            else if (left) v = (sV + 2) >> 2;
+            else v = (sH + 2) >> 2;
+        } else if (bx == 1) { // xO > 0, yO == 0: prefers top
+            v = up ? ((sH + 2) >> 2) : ((sV + 2) >> 2);
+        } else {              // xO == 0, yO > 0: prefers left
+            v = left ? ((sV + 2) >> 2) : ((sH + 2) >> 2);
+        }
+        p0 = p1 = v;
+    } else if (mode == 1) {
+        if (left) p0 = p1 = W.LcolC[pl][y];
+    } else if (mode == 2) {
+        if (up) { p0 = TC[8 + x0]; p1 = TC[8 + x0 + 1]; }
+    } else if (mode == 3) {
+        if (left && up) {
+            const int cor = TC[7];
+            const uint32_t tw[2] = {topv.x, topv.y}, lw[2] = {lefv.x, lefv.y};
+            int H = 0, V = 0;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int hi = 4 + i, lo = 2 - i;
+                const int th = (tw[hi >> 2] >> ((hi & 3) * 8)) & 255;
+                const int lh = (lw[hi >> 2] >> ((hi & 3) * 8)) & 255;
+                const int tl = (lo < 0) ? cor : (int)((tw[0] >> (lo * 8)) & 255);
+                const int ll = (lo < 0) ? cor : (int)((lw[0] >> (lo * 8)) & 255);
+                H += (i + 1) * (th - tl);
+                V += (i + 1) * (lh - ll);
+            }
+            const int a = 16 * ((int)(lefv.y >> 24) + (int)(topv.y >> 24));
+            const int b = (34 * H + 32) >> 6;
+            const int c = (34 * V + 32) >> 6;
+            p0 = clip255((a + b * (x0 - 3) + c * (y - 3) + 16) >> 5);
+            p1 = clip255((a + b * (x0 + 1 - 3) + c * (y - 3) + 16) >> 5);
+        }
+    }
+    if (has_res) {
+        const int rr = *reinterpret_cast<const int *>(&W.res[256 + pl * 64 + y * 8 + x0]);
+        p0 += (int16_t)(rr & 0xffff); p1 += rr >> 16;
+    }
+    const uint16_t out = (uint16_t)(clip255(p0) | (clip255(p1) << 8));
+    *reinterpret_cast<uint16_t *>(&W.TC[pl][(y + 1) * 16 + 8 + x0]) = out;
+    WAVE_SYNC();
+}
+
+// ---------------------------------------------------------------------------
+// the reconstruction kernel
+// ---------------------------------------------------------------------------
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void recon_rows_kernel(ReconArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int W = a.width_mbs, H = a.height_mbs;
+    BlockLds &B = *reinterpret_cast<BlockLds *>(smem);
+    uint8_t *line_y = smem + sizeof(BlockLds);
+    uint8_t *line_cb = line_y + W * 16;
+    uint8_t *line_cr = line_cb + W * 8;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63;
+    WaveLds &Wv = *reinterpret_cast<WaveLds *>(line_cr + W * 8 + (size_t)wave * sizeof(WaveLds));
+    const int frame = blockIdx.x;
+
+    // ---- one-time table setup ----
+    for (int i = threadIdx.x; i < 18; i += NW * 64) B.ls4[i] = 16 * c_v4x4[i];
+    for (int i = threadIdx.x; i < 36; i += NW * 64) B.ls8[i] = 16 * c_v8x8[i];
+    for (int i = threadIdx.x; i < 64; i += NW * 64) {
+        const int r = i >> 3, c = i & 7;
+        int k;
+        if ((r % 4 == 0) && (c % 4 == 0)) k = 0;
+        else if ((r % 2 == 1) && (c % 2 == 1)) k = 1;
+        else if ((r % 4 == 2) && (c % 4 == 2)) k = 2;
+        else if (((r % 4 == 0) && (c % 2 == 1)) || ((r % 2 == 1) && (c % 4 == 0))) k = 3;
+        else if (((r % 4 == 0) && (c % 4 == 2)) || ((r % 4 == 2) && (c % 4 == 0))) k = 4;
+        else k = 5;
+        B.cls8[i] = (uint8_t)k;
+    }
+    for (int i = threadIdx.x; i < 9 * 16; i += NW * 64) B.tab4[i] = (uint8_t)mode_entry(4, i >> 4, i & 3, (i >> 2) & 3);
+    for (int i = threadIdx.x; i < 9 * 64; i += NW * 64) B.tab8[i] = (uint8_t)mode_entry(8, i >> 6, i & 7, (i >> 3) & 7);
+    if (threadIdx.x < 16) B.progress[threadIdx.x] = 0;
+    if (threadIdx.x == 16) B.abort_flag = 0;
+    __syncthreads();
+
+    const uint8_t *fpacked = a.packed + (size_t)frame * W * H * MVHP_MB_BYTES;
+    uint8_t *fy = a.yuv + (size_t)frame * W * H * 384;
+    uint8_t *fcb = fy + (size_t)W * H * 256;
+    uint8_t *fcr = fcb + (size_t)W * H * 64;
+    const int pitch = W * 16, cpitch = W * 8;
+    const int up_wave = (wave + NW - 1) % NW;
+    volatile int *progress = B.progress;
+    volatile int *abort_flag = &B.abort_flag;
+
+    int done = 0; // macroblocks completed by this wave
+    for (int row = wave; row < H; row += NW) {
+        const int pass = row / NW;
+        const int up_base = ((wave == 0) ? (pass - 1) : pass) * W; // MBs the upper wave finished before its row (row-1)
+        const bool Bv = row > 0;
+        for (int mbx = 0; mbx < W; mbx++) {
+            const uint8_t *mbp = fpacked + (size_t)(row * W + mbx) * MVHP_MB_BYTES;
+            // header: wave-uniform -> scalar loads
+            const uint32_t h0 = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const uint32_t *>(mbp));
+            const uint32_t h1 = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const uint32_t *>(mbp + 4));
+            const uint32_t nz = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const uint32_t *>(mbp + 8));
+            const int kind = h0 & 255, qpy = (h0 >> 8) & 255;
+            const int cmode = (h0 >> 24) & 255, i16mode = h1 & 255;
+            const bool A = mbx > 0, C = Bv && (mbx < W - 1), D = A && Bv;
+
+            int qpc[2];
+#pragma unroll
+            for (int c = 0; c < 2; c++) { // derivChromaQP, h264_transform.c:598-637
+                int qpi = qpy + (c ? a.cqp_off_cr : a.cqp_off_cb);
+                qpi = min(max(qpi, 0), 51);
+                qpc[c] = (qpi > 29) ? (int)c_qpc[qpi - 30] : qpi;
+            }
+
+            // Intra16x16 at QP'Y == 36 yields a non-zero DC term even from all-zero levels
+            // (h264_transform.c:797-808), so the residual stage cannot be skipped there.
+            const bool quirk36 = (kind == MVHP_KIND_I16x16) && (qpy == 36);
+            const bool res_luma = ((nz & 0xffffu) != 0) || quirk36, res_chroma = (nz & 0xff0000u) != 0;
+            if (res_luma || res_chroma) residual_stage(Wv, B, mbp, lane, kind, qpy, qpc[0], qpc[1]);
+            // (when only one of luma/chroma has levels the other half of res holds zeros
+            //  produced by residual_stage from zero coefficients)
+
+            // ---- wait for the row above: needs columns <= min(mbx+1, W-1) ----
+            if (Bv) {
+                const int need = up_base + min(mbx + 2, W);
+                int spins = 0;
+                while (progress[up_wave] < need) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > (1 << 22) || *abort_flag) {
+                        if (lane == 0) { *abort_flag = 1; atomicOr(a.err, 1u); }
+                        return;
+                    }
+                }
+                asm volatile("" ::: "memory");
+                // top neighbours: luma 16 + 8 up-right, chroma 8 + 8
+                if (lane < 4) *reinterpret_cast<uint32_t *>(&Wv.T[16 + lane * 4]) =
+                        *reinterpret_cast<const uint32_t *>(&line_y[mbx * 16 + lane * 4]);
+                else if (lane < 6) { if (C) *reinterpret_cast<uint32_t *>(&Wv.T[32 + (lane - 4) * 4]) =
+                        *reinterpret_cast<const uint32_t *>(&line_y[(mbx + 1) * 16 + (lane - 4) * 4]); }
+                else if (lane < 8) *reinterpret_cast<uint32_t *>(&Wv.TC[0][8 + (lane - 6) * 4]) =
+                        *reinterpret_cast<const uint32_t *>(&line_cb[mbx * 8 + (lane - 6) * 4]);
+                else if (lane < 10) *reinterpret_cast<uint32_t *>(&Wv.TC[1][8 + (lane - 8) * 4]) =
+                        *reinterpret_cast<const uint32_t *>(&line_cr[mbx * 8 + (lane - 8) * 4]);
+            }
+            WAVE_SYNC();
+
+            // ---- luma ----
+            if (kind == MVHP_KIND_I16x16) {
+                predict_16x16(Wv, lane, i16mode, A, Bv, res_luma);
+            } else if (kind == MVHP_KIND_I4x4) {
+                const uint32_t m0 = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const uint32_t *>(mbp + 12));
+                const uint32_t m1 = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const uint32_t *>(mbp + 16));
+                const uint32_t m2 = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const uint32_t *>(mbp + 20));
+                const uint32_t m3 = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const uint32_t *>(mbp + 24));
+                for (int blk = 0; blk < 16; blk++) {
+                    const uint32_t mw = (blk < 4) ? m0 : (blk < 8) ? m1 : (blk < 12) ? m2 : m3;
+                    const int mode = (mw >> ((blk & 3) * 8)) & 255;
+                    predict_4x4(Wv, B, lane, blk, mode, A, Bv, C, D, res_luma);
+                }
+            } else {
+                const uint32_t m0 = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const uint32_t *>(mbp + 12));
+                for (int blk = 0; blk < 4; blk++)
+                    predict_8x8(Wv, B, lane, blk, (m0 >> (blk * 8)) & 255, A, Bv, C, D, res_luma);
+            }
+            // ---- chroma ----
+            predict_chroma(Wv, lane, cmode, A, Bv, res_chroma);
+
+            // ---- write-out: planes (coalesced 16-byte luma rows / 8-byte chroma rows) ----
+            {
+                const int y = lane >> 2, q = lane & 3;
+                *reinterpret_cast<uint32_t *>(&fy[(size_t)(row * 16 + y) * pitch + mbx * 16 + q * 4]) =
+                    *reinterpret_cast<const uint32_t *>(&Wv.T[(y + 1) * 32 + 16 + q * 4]);
+                if (lane < 32) {
+                    const int pl = lane >> 4, cy = (lane & 15) >> 1, hf = lane & 1;
+                    uint8_t *dst = pl ? fcr : fcb;
+                    *reinterpret_cast<uint32_t *>(&dst[(size_t)(row * 8 + cy) * cpitch + mbx * 8 + hf * 4]) =
+                        *reinterpret_cast<const uint32_t *>(&Wv.TC[pl][(cy + 1) * 16 + 8 + hf * 4]);
+                }
+            }
+            // ---- neighbour state for the next macroblock / next row ----
+            // corners first (old top-right sample), then left columns, then the line buffer.
+            uint32_t keep = 0;
+            if (lane == 0) keep = Wv.T[31];
+            else if (lane == 1) keep = Wv.TC[0][15];
+            else if (lane == 2) keep = Wv.TC[1][15];
+            else if (lane >= 16 && lane < 32) keep = Wv.T[(lane - 16 + 1) * 32 + 31];
+            else if (lane >= 32 && lane < 48) keep = Wv.TC[(lane - 32) >> 3][(((lane - 32) & 7) + 1) * 16 + 15];
+            uint32_t bot = 0;
+            if (lane >= 48 && lane < 52) bot = *reinterpret_cast<const uint32_t *>(&Wv.T[16 * 32 + 16 + (lane - 48) * 4]);
+            else if (lane >= 52 && lane < 54) bot = *reinterpret_cast<const uint32_t *>(&Wv.TC[0][8 * 16 + 8 + (lane - 52) * 4]);
+            else if (lane >= 54 && lane < 56) bot = *reinterpret_cast<const uint32_t *>(&Wv.TC[1][8 * 16 + 8 + (lane - 54) * 4]);
+            WAVE_SYNC();
+            if (lane == 0) Wv.T[15] = (uint8_t)keep;
+            else if (lane == 1) Wv.TC[0][7] = (uint8_t)keep;
+            else if (lane == 2) Wv.TC[1][7] = (uint8_t)keep;
+            else if (lane >= 16 && lane < 32) { Wv.T[(lane - 16 + 1) * 32 + 15] = (uint8_t)keep; Wv.Lcol[lane - 16] = (uint8_t)keep; }
+            else if (lane >= 32 && lane < 48) {
+                const int pl = (lane - 32) >> 3, cy = (lane - 32) & 7;
+                Wv.TC[pl][(cy + 1) * 16 + 7] = (uint8_t)keep; Wv.LcolC[pl][cy] = (uint8_t)keep;
+            }
+            else if (lane >= 48 && lane < 52) *reinterpret_cast<uint32_t *>(&line_y[mbx * 16 + (lane - 48) * 4]) = bot;
+            else if (lane >= 52 && lane < 54) *reinterpret_cast<uint32_t *>(&line_cb[mbx * 8 + (lane - 52) * 4]) = bot;
+            else if (lane >= 54 && lane < 56) *reinterpret_cast<uint32_t *>(&line_cr[mbx * 8 + (lane - 54) * 4]) = bot;
+            // ---- publish ----
+            done++;
+            // LDS operations of one wave complete in order; the explicit wait makes the line-buffer
+            // writes land before the counter without waiting for the global plane stores (vmcnt).
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (lane == 0) progress[wave] = done;
+            WAVE_SYNC();
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// colour conversion (export_utils.c:209-324): 2x2 nearest chroma replicate and
+// the integer formula of :300-302.  One thread per 4 horizontal samples.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ycbcr_to_rgb_kernel(ColorArgs a)
+{
+    const int Wp = a.width_mbs * 16, Hp = a.height_mbs * 16;
+    const int quads_per_row = Wp >> 2;
+    const size_t quads_per_frame = (size_t)quads_per_row * Hp;
+    const size_t total = quads_per_frame * a.n_frames;
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+        const int frame = (int)(t / quads_per_frame);
+        const size_t r = t - (size_t)frame * quads_per_frame;
+        const int y = (int)(r / quads_per_row), xq = (int)(r - (size_t)y * quads_per_row);
+        const uint8_t *fy = a.yuv + (size_t)frame * Wp * Hp * 3 / 2;
+        const uint8_t *fcb = fy + (size_t)Wp * Hp;
+        const uint8_t *fcr = fcb + (size_t)(Wp >> 1) * (Hp >> 1);
+        const uint32_t yw = *reinterpret_cast<const uint32_t *>(&fy[(size_t)y * Wp + xq * 4]);
+        const uint32_t cbw = *reinterpret_cast<const uint16_t *>(&fcb[(size_t)(y >> 1) * (Wp >> 1) + xq * 2]);
+        const uint32_t crw = *reinterpret_cast<const uint16_t *>(&fcr[(size_t)(y >> 1) * (Wp >> 1) + xq * 2]);
+        uint8_t o[12];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int l = (yw >> (q * 8)) & 255;
+            const int cb = (cbw >> ((q >> 1) * 8)) & 255, cr = (crw >> ((q >> 1) * 8)) & 255;
+            const int ly = (298 * l) >> 8;
+            o[q * 3 + 0] = (uint8_t)clip255(ly + ((408 * cr) >> 8) - 222);
+            o[q * 3 + 1] = (uint8_t)clip255(ly - ((100 * cb) >> 8) - ((208 * cr) >> 8) + 135);
+            o[q * 3 + 2] = (uint8_t)clip255(ly + ((516 * cb) >> 8) - 276);
+        }
+        uint32_t *dst = reinterpret_cast<uint32_t *>(a.rgb + (size_t)frame * Wp * Hp * 3 + ((size_t)y * Wp + xq * 4) * 3);
+        dst[0] = o[0] | (o[1] << 8) | (o[2] << 16) | ((uint32_t)o[3] << 24);
+        dst[1] = o[4] | (o[5] << 8) | (o[6] << 16) | ((uint32_t)o[7] << 24);
+        dst[2] = o[8] | (o[9] << 8) | (o[10] << 16) | ((uint32_t)o[11] << 24);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// launch wrappers
+// ---------------------------------------------------------------------------
+size_t recon_lds_bytes(int width_mbs, int nw)
+{
+    return sizeof(BlockLds) + (size_t)width_mbs * 32 + (size_t)nw * sizeof(WaveLds);
+}
+
+hipError_t launch_recon(const ReconArgs &a, int n_frames, int nw, hipStream_t stream)
+{
+    const size_t lds = recon_lds_bytes(a.width_mbs, nw);
+    hipError_t e = hipSuccess;
+    switch (nw) {
+    case 4:
+        e = hipFuncSetAttribute((const void *)recon_rows_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(recon_rows_kernel<4>, dim3(n_frames), dim3(4 * 64), lds, stream, a);
+        break;
+    case 8:
+        e = hipFuncSetAttribute((const void *)recon_rows_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(recon_rows_kernel<8>, dim3(n_frames), dim3(8 * 64), lds, stream, a);
+        break;
+    case 16:
+        e = hipFuncSetAttribute((const void *)recon_rows_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(recon_rows_kernel<16>, dim3(n_frames), dim3(16 * 64), lds, stream, a);
+        break;
+    default:
+        return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_color(const ColorArgs &a, hipStream_t stream)
+{
+    const size_t total = (size_t)a.width_mbs * 4 * a.height_mbs * 16 * a.n_frames;
+    size_t blocks = (total + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(ycbcr_to_rgb_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, a);
+    return hipGetLastError();
+}
+
+} // namespace mvhp

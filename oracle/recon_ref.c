@@ -1,0 +1,765 @@
+/*
+ * oracle/recon_ref.c -- TEST INFRASTRUCTURE ONLY.
+ *
+ * Plain-C CPU restatement of the reconstruction half of MiniVideo's H.264
+ * intra decoder (everything the build moves to the GPU).  It is the checker
+ * that tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg compare
+ * the HIP kernels against; the product (libminivideo.so) never links, loads or
+ * calls anything in this directory.
+ *
+ * Pinning status: the reference cannot be compiled in this image without
+ * fabricating a stand-in for its CMake-generated (WIN32-only) header
+ * `build/minivideo_Export.h` (avcodecs.h:29), so there is no oracle/_ref.
+ * This restatement is pinned by the reference-output known-answer vectors
+ * recorded in SURVEY.md Appendix A (tests/golden/kat_*), and is otherwise
+ * "parity unpinned": it follows the reference source text function by
+ * function (citations below, relative to minivideo/src/decoder/h264/).
+ *
+ * Input: the packed macroblock records of include/minivideo_hotpath.h.
+ * Output: planar Y|Cb|Cr of the uncropped picture (export.c:65-188) and RGB8
+ * (export_utils.c:209-324).
+ *
+ * Integer semantics: the reference computes in C `int`; where it overflows or
+ * shifts by a negative count (h264_transform.c:797-808 at QP'Y == 36) the
+ * observable x86-64/gcc behaviour is two's-complement wrap with the shift
+ * count taken modulo 32 -- restated here with explicit unsigned arithmetic
+ * (and built with -fwrapv) so that the checker itself has no UB.
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../include/minivideo_hotpath.h"
+
+#define ORC_EXPORT __attribute__((visibility("default")))
+
+/* ---- small helpers ------------------------------------------------------ */
+
+static inline int clip255(int x) { return x < 0 ? 0 : (x > 255 ? 255 : x); } /* utils.c:407 */
+static inline int wshl(int v, int s) { return (int)((uint32_t)v << (s & 31)); }
+static inline int wsar(int v, int s) { return v >> (s & 31); }
+
+/* normAdjust tables, h264.c:419-493; flat scaling lists (16) are the only
+ * ones the reference decodes correctly, so
+ * LevelScale = 16 * normAdjust (h264_transform.c:645-741). */
+static const int v4x4[6][3] = {
+    {10, 16, 13}, {11, 18, 14}, {13, 20, 16}, {14, 23, 18}, {16, 25, 20}, {18, 29, 23}};
+static const int v8x8[6][6] = {
+    {20, 18, 32, 19, 25, 24}, {22, 19, 35, 21, 28, 26}, {26, 23, 42, 24, 33, 31},
+    {28, 25, 45, 26, 35, 33}, {32, 28, 51, 30, 40, 38}, {36, 32, 58, 34, 46, 43}};
+
+static int level_scale4(int q, int i, int j)
+{
+    int k;
+    if ((i % 2 == 0) && (j % 2 == 0)) k = 0;
+    else if ((i % 2 == 1) && (j % 2 == 1)) k = 1;
+    else k = 2;
+    return 16 * v4x4[q][k];
+}
+
+static int level_scale8(int q, int i, int j)
+{
+    int k;
+    if ((i % 4 == 0) && (j % 4 == 0)) k = 0;
+    else if ((i % 2 == 1) && (j % 2 == 1)) k = 1;
+    else if ((i % 4 == 2) && (j % 4 == 2)) k = 2;
+    else if (((i % 4 == 0) && (j % 2 == 1)) || ((i % 2 == 1) && (j % 4 == 0))) k = 3;
+    else if (((i % 4 == 0) && (j % 4 == 2)) || ((i % 4 == 2) && (j % 4 == 0))) k = 4;
+    else k = 5;
+    return 16 * v8x8[q][k];
+}
+
+/* Table 8-15, h264_transform.c:71 */
+static const int qpc_table[22] = {29, 30, 31, 32, 32, 33, 34, 34, 35, 35, 36,
+                                  36, 37, 37, 37, 38, 38, 38, 39, 39, 39, 39};
+
+/* derivChromaQP, h264_transform.c:598-637 (8-bit: QpBdOffsetC = 0) */
+static int chroma_qp(int qpy, int offset)
+{
+    int qpi = qpy + offset;
+    if (qpi < 0) qpi = 0;
+    if (qpi > 51) qpi = 51;
+    return qpi > 29 ? qpc_table[qpi - 30] : qpi;
+}
+
+/* InverseLuma4x4BlkScan, h264_spatial.c:210 */
+static void blk4_xy(int blk, int *x, int *y)
+{
+    *x = ((blk / 4) % 2) * 8 + ((blk % 4) % 2) * 4;
+    *y = ((blk / 4) / 2) * 8 + ((blk % 4) / 2) * 4;
+}
+
+/* ---- per-picture state -------------------------------------------------- */
+
+typedef struct {
+    int W, H;                 /* in macroblocks */
+    int pitch, cpitch;        /* plane pitches  */
+    uint8_t *y, *cb, *cr;
+    int cqp_off[2];
+    int mbx, mby;             /* current macroblock */
+} pic_t;
+
+/* deriv_neighbouringlocations (h264_spatial.c:739-786) + availability by
+ * geometry (h264_spatial.c:333-416; one slice per picture): returns 1 and the
+ * sample when luma location (xN,yN), relative to the current macroblock, lies
+ * in an available macroblock. maxW = 16 (luma) or 8 (chroma). */
+static int neigh_sample(const pic_t *p, const uint8_t *plane, int pitch, int maxW, int xN, int yN, int *out)
+{
+    int mx = p->mbx, my = p->mby;
+    if (yN > maxW - 1) return 0;
+    if (xN < 0 && yN < 0) { mx -= 1; my -= 1; }                 /* D */
+    else if (xN < 0) { mx -= 1; }                               /* A */
+    else if (xN <= maxW - 1 && yN < 0) { my -= 1; }             /* B */
+    else if (xN <= maxW - 1) { /* current macroblock */ }
+    else if (yN < 0) { mx += 1; my -= 1; }                      /* C */
+    else return 0;                                              /* right of MB: not available */
+    if (mx < 0 || my < 0 || mx >= p->W) return 0;
+    {
+        int X = p->mbx * maxW + xN, Y = p->mby * maxW + yN;
+        *out = plane[(size_t)Y * pitch + X];
+    }
+    return 1;
+}
+
+/* ---- residual: scaling + transforms (h264_transform.c) ------------------ */
+
+/* idct4x4, h264_transform.c:1145-1191 */
+static void idct4x4(const int d[4][4], int r[4][4])
+{
+    int e[4][4], f[4][4], g[4][4], h[4][4], i, j;
+    for (i = 0; i < 4; i++) {
+        e[i][0] = d[i][0] + d[i][2];
+        e[i][1] = d[i][0] - d[i][2];
+        e[i][2] = (d[i][1] >> 1) - d[i][3];
+        e[i][3] = d[i][1] + (d[i][3] >> 1);
+    }
+    for (i = 0; i < 4; i++) {
+        f[i][0] = e[i][0] + e[i][3];
+        f[i][1] = e[i][1] + e[i][2];
+        f[i][2] = e[i][1] - e[i][2];
+        f[i][3] = e[i][0] - e[i][3];
+    }
+    for (j = 0; j < 4; j++) {
+        g[0][j] = f[0][j] + f[2][j];
+        g[1][j] = f[0][j] - f[2][j];
+        g[2][j] = (f[1][j] >> 1) - f[3][j];
+        g[3][j] = f[1][j] + (f[3][j] >> 1);
+    }
+    for (j = 0; j < 4; j++) {
+        h[0][j] = g[0][j] + g[3][j];
+        h[1][j] = g[1][j] + g[2][j];
+        h[2][j] = g[1][j] - g[2][j];
+        h[3][j] = g[0][j] - g[3][j];
+    }
+    for (i = 0; i < 4; i++)
+        for (j = 0; j < 4; j++)
+            r[i][j] = (h[i][j] + 32) >> 6;
+}
+
+/* quant4x4 + idct4x4 = transform_4x4_residual, h264_transform.c:1049-1134.
+ * keep_dc: Intra_16x16 luma or any chroma block (d[0][0] = c[0][0], :1126). */
+static void residual4x4(const int c[4][4], int qP, int keep_dc, int r[4][4])
+{
+    int d[4][4], i, j, m = qP % 6, s = qP / 6;
+    if (qP > 23) {
+        for (i = 0; i < 4; i++)
+            for (j = 0; j < 4; j++)
+                d[i][j] = wshl(c[i][j] * level_scale4(m, i, j), s - 4);
+    } else {
+        int rnd = 1 << (3 - s);
+        for (i = 0; i < 4; i++)
+            for (j = 0; j < 4; j++)
+                d[i][j] = (c[i][j] * level_scale4(m, i, j) + rnd) >> (4 - s);
+    }
+    if (keep_dc) d[0][0] = c[0][0];
+    idct4x4(d, r);
+}
+
+/* quant8x8 + idct8x8 = transform_8x8_residual, h264_transform.c:1205-1383 */
+static void residual8x8(const int c[8][8], int qP, int r[8][8])
+{
+    int d[8][8], e[8][8], f[8][8], g[8][8], h[8][8], k[8][8], mm[8][8];
+    int i, j, m = qP % 6, s = qP / 6;
+    if (qP > 35) {
+        for (i = 0; i < 8; i++)
+            for (j = 0; j < 8; j++)
+                d[i][j] = wshl(c[i][j] * level_scale8(m, i, j), s - 6);
+    } else {
+        int rnd = 1 << (5 - s);
+        for (i = 0; i < 8; i++)
+            for (j = 0; j < 8; j++)
+                d[i][j] = (c[i][j] * level_scale8(m, i, j) + rnd) >> (6 - s);
+    }
+    for (i = 0; i < 8; i++) {
+        e[i][0] = d[i][0] + d[i][4];
+        e[i][1] = -d[i][3] + d[i][5] - d[i][7] - (d[i][7] >> 1);
+        e[i][2] = d[i][0] - d[i][4];
+        e[i][3] = d[i][1] + d[i][7] - d[i][3] - (d[i][3] >> 1);
+        e[i][4] = (d[i][2] >> 1) - d[i][6];
+        e[i][5] = -d[i][1] + d[i][7] + d[i][5] + (d[i][5] >> 1);
+        e[i][6] = d[i][2] + (d[i][6] >> 1);
+        e[i][7] = d[i][3] + d[i][5] + d[i][1] + (d[i][1] >> 1);
+    }
+    for (i = 0; i < 8; i++) {
+        f[i][0] = e[i][0] + e[i][6];
+        f[i][1] = e[i][1] + (e[i][7] >> 2);
+        f[i][2] = e[i][2] + e[i][4];
+        f[i][3] = e[i][3] + (e[i][5] >> 2);
+        f[i][4] = e[i][2] - e[i][4];
+        f[i][5] = (e[i][3] >> 2) - e[i][5];
+        f[i][6] = e[i][0] - e[i][6];
+        f[i][7] = e[i][7] - (e[i][1] >> 2);
+    }
+    for (i = 0; i < 8; i++) {
+        g[i][0] = f[i][0] + f[i][7];
+        g[i][1] = f[i][2] + f[i][5];
+        g[i][2] = f[i][4] + f[i][3];
+        g[i][3] = f[i][6] + f[i][1];
+        g[i][4] = f[i][6] - f[i][1];
+        g[i][5] = f[i][4] - f[i][3];
+        g[i][6] = f[i][2] - f[i][5];
+        g[i][7] = f[i][0] - f[i][7];
+    }
+    for (j = 0; j < 8; j++) {
+        h[0][j] = g[0][j] + g[4][j];
+        h[1][j] = -g[3][j] + g[5][j] - g[7][j] - (g[7][j] >> 1);
+        h[2][j] = g[0][j] - g[4][j];
+        h[3][j] = g[1][j] + g[7][j] - g[3][j] - (g[3][j] >> 1);
+        h[4][j] = (g[2][j] >> 1) - g[6][j];
+        h[5][j] = -g[1][j] + g[7][j] + g[5][j] + (g[5][j] >> 1);
+        h[6][j] = g[2][j] + (g[6][j] >> 1);
+        h[7][j] = g[3][j] + g[5][j] + g[1][j] + (g[1][j] >> 1);
+    }
+    for (j = 0; j < 8; j++) {
+        k[0][j] = h[0][j] + h[6][j];
+        k[1][j] = h[1][j] + (h[7][j] >> 2);
+        k[2][j] = h[2][j] + h[4][j];
+        k[3][j] = h[3][j] + (h[5][j] >> 2);
+        k[4][j] = h[2][j] - h[4][j];
+        k[5][j] = (h[3][j] >> 2) - h[5][j];
+        k[6][j] = h[0][j] - h[6][j];
+        k[7][j] = h[7][j] - (h[1][j] >> 2);
+    }
+    for (j = 0; j < 8; j++) {
+        mm[0][j] = k[0][j] + k[7][j];
+        mm[1][j] = k[2][j] + k[5][j];
+        mm[2][j] = k[4][j] + k[3][j];
+        mm[3][j] = k[6][j] + k[1][j];
+        mm[4][j] = k[6][j] - k[1][j];
+        mm[5][j] = k[4][j] - k[3][j];
+        mm[6][j] = k[2][j] - k[5][j];
+        mm[7][j] = k[0][j] - k[7][j];
+    }
+    for (i = 0; i < 8; i++)
+        for (j = 0; j < 8; j++)
+            r[i][j] = (mm[i][j] + 32) >> 6;
+}
+
+/* transform_16x16_lumadc, h264_transform.c:756-812 -- including the
+ * `qP > 36` test (the standard says >= 36): at QP'Y == 36 the reference
+ * evaluates (f*LS + (1 << -1)) >> 0. */
+static void luma_dc(const int c[4][4], int qP, int dcY[4][4])
+{
+    static const int H4[4][4] = {{1, 1, 1, 1}, {1, 1, -1, -1}, {1, -1, -1, 1}, {1, -1, 1, -1}};
+    int f1[4][4] = {{0}}, f2[4][4] = {{0}}, i, j, k;
+    int m = qP % 6, s = qP / 6, ls = level_scale4(m, 0, 0);
+    for (i = 0; i < 4; i++)
+        for (j = 0; j < 4; j++)
+            for (k = 0; k < 4; k++)
+                f1[i][j] += H4[i][k] * c[k][j];
+    for (i = 0; i < 4; i++)
+        for (j = 0; j < 4; j++)
+            for (k = 0; k < 4; k++)
+                f2[i][j] += f1[i][k] * H4[k][j];
+    if (qP > 36) {
+        for (i = 0; i < 4; i++)
+            for (j = 0; j < 4; j++)
+                dcY[i][j] = wshl(f2[i][j] * ls, s - 6);
+    } else {
+        for (i = 0; i < 4; i++)
+            for (j = 0; j < 4; j++)
+                dcY[i][j] = wsar((int)((uint32_t)(f2[i][j] * ls) + ((uint32_t)1 << ((5 - s) & 31))), 6 - s);
+    }
+}
+
+/* transform_2x2_chromadc, h264_transform.c:827-860, 924-936, 988-1005 */
+static void chroma_dc(const int c[4], int qPc, int dcC[4])
+{
+    int f[4], ls = level_scale4(qPc % 6, 0, 0), k;
+    f[0] = c[0] + c[1] + c[2] + c[3];
+    f[1] = c[0] - c[1] + c[2] - c[3];
+    f[2] = c[0] + c[1] - c[2] - c[3];
+    f[3] = c[0] - c[1] - c[2] + c[3];
+    for (k = 0; k < 4; k++)
+        dcC[k] = wshl(f[k] * ls, qPc / 6) >> 5;
+}
+
+/* ---- luma 4x4 prediction (h264_intra_prediction.c:315-960) -------------- */
+
+typedef struct {
+    int left, up_left, up, up_right;
+    int pv[17]; /* pv[0] = p[-1,-1], pv[y+1] = p[-1,y] */
+    int ph[18]; /* ph[0] = p[-1,-1], ph[x+1] = p[x,-1] */
+} edge_t;
+
+static void pred4x4(const edge_t *ip, int mode, int pred[4][4] /* [x][y] */)
+{
+    int x, y;
+    memset(pred, 0, 16 * sizeof(int)); /* unavailable neighbours leave pred = 0 (:442, result ignored) */
+    switch (mode) {
+    case 0:
+        if (ip->up) for (x = 0; x < 4; x++) for (y = 0; y < 4; y++) pred[x][y] = ip->ph[x + 1];
+        break;
+    case 1:
+        if (ip->left) for (x = 0; x < 4; x++) for (y = 0; y < 4; y++) pred[x][y] = ip->pv[y + 1];
+        break;
+    case 2: {
+        int sumH = ip->ph[1] + ip->ph[2] + ip->ph[3] + ip->ph[4];
+        int sumV = ip->pv[1] + ip->pv[2] + ip->pv[3] + ip->pv[4];
+        int v;
+        if (ip->left && ip->up) v = (sumH + sumV + 4) >> 3;
+        else if (ip->left) v = (sumV + 2) >> 2;
+        else if (ip->up) v = (sumH + 2) >> 2;
+        else v = 128;
+        for (x = 0; x < 4; x++) for (y = 0; y < 4; y++) pred[x][y] = v;
+        break;
+    }
+    case 3:
+        if (ip->up && ip->up_right)
+            for (x = 0; x < 4; x++) for (y = 0; y < 4; y++) {
+                if (x == 3 && y == 3) pred[x][y] = (ip->ph[7] + 3 * ip->ph[8] + 2) >> 2;
+                else pred[x][y] = (ip->ph[x + y + 1] + 2 * ip->ph[x + y + 2] + ip->ph[x + y + 3] + 2) >> 2;
+            }
+        break;
+    case 4:
+        if (ip->left && ip->up_left && ip->up)
+            for (x = 0; x < 4; x++) for (y = 0; y < 4; y++) {
+                if (x > y) pred[x][y] = (ip->ph[x - y - 1] + 2 * ip->ph[x - y] + ip->ph[x - y + 1] + 2) >> 2;
+                else if (x < y) pred[x][y] = (ip->pv[y - x - 1] + 2 * ip->pv[y - x] + ip->pv[y - x + 1] + 2) >> 2;
+                else pred[x][y] = (ip->ph[1] + 2 * ip->pv[0] + ip->pv[1] + 2) >> 2;
+            }
+        break;
+    case 5:
+        if (ip->left && ip->up_left && ip->up)
+            for (x = 0; x < 4; x++) for (y = 0; y < 4; y++) {
+                int z = 2 * x - y;
+                if (z > -1) {
+                    if (z % 2 == 0) pred[x][y] = (ip->ph[x - (y >> 1)] + ip->ph[x - (y >> 1) + 1] + 1) >> 1;
+                    else pred[x][y] = (ip->ph[x - (y >> 1) - 1] + 2 * ip->ph[x - (y >> 1)] + ip->ph[x - (y >> 1) + 1] + 2) >> 2;
+                } else if (z == -1) pred[x][y] = (ip->pv[1] + 2 * ip->pv[0] + ip->ph[1] + 2) >> 2;
+                else pred[x][y] = (ip->pv[y] + 2 * ip->pv[y - 1] + ip->pv[y - 2] + 2) >> 2;
+            }
+        break;
+    case 6:
+        if (ip->left && ip->up_left && ip->up)
+            for (x = 0; x < 4; x++) for (y = 0; y < 4; y++) {
+                int z = 2 * y - x;
+                if (z > -1) {
+                    if (z % 2 == 0) pred[x][y] = (ip->pv[y - (x >> 1)] + ip->pv[y - (x >> 1) + 1] + 1) >> 1;
+                    else pred[x][y] = (ip->pv[y - (x >> 1) - 1] + 2 * ip->pv[y - (x >> 1)] + ip->pv[y - (x >> 1) + 1] + 2) >> 2;
+                } else if (z == -1) pred[x][y] = (ip->pv[1] + 2 * ip->pv[0] + ip->ph[1] + 2) >> 2;
+                else pred[x][y] = (ip->ph[x] + 2 * ip->ph[x - 1] + ip->ph[x - 2] + 2) >> 2;
+            }
+        break;
+    case 7:
+        if (ip->up && ip->up_right)
+            for (x = 0; x < 4; x++) for (y = 0; y < 4; y++) {
+                if (y % 2 == 0) pred[x][y] = (ip->ph[x + (y >> 1) + 1] + ip->ph[x + (y >> 1) + 2] + 1) >> 1;
+                else pred[x][y] = (ip->ph[x + (y >> 1) + 1] + 2 * ip->ph[x + (y >> 1) + 2] + ip->ph[x + (y >> 1) + 3] + 2) >> 2;
+            }
+        break;
+    case 8:
+        if (ip->left)
+            for (x = 0; x < 4; x++) for (y = 0; y < 4; y++) {
+                int z = x + 2 * y;
+                if (z < 5 && z % 2 == 0) pred[x][y] = (ip->pv[y + (x >> 1) + 1] + ip->pv[y + (x >> 1) + 2] + 1) >> 1;
+                else if (z == 1 || z == 3) pred[x][y] = (ip->pv[y + (x >> 1) + 1] + 2 * ip->pv[y + (x >> 1) + 2] + ip->pv[y + (x >> 1) + 3] + 2) >> 2;
+                else if (z == 5) pred[x][y] = (ip->pv[3] + 3 * ip->pv[4] + 2) >> 2;
+                else pred[x][y] = ip->pv[4];
+            }
+        break;
+    default:
+        break;
+    }
+}
+
+/* Intra_4x4_pred_sample neighbour fetch, h264_intra_prediction.c:340-439 */
+static void fetch_edges(const pic_t *p, int xO, int yO, int n /* 4 or 8 */, int blk, edge_t *ip)
+{
+    int x, y, v;
+    memset(ip, 0, sizeof(*ip));
+    if (neigh_sample(p, p->y, p->pitch, 16, xO - 1, yO - 1, &v)) { ip->up_left = 1; ip->pv[0] = ip->ph[0] = v; }
+    for (y = 0; y < n; y++)
+        if (neigh_sample(p, p->y, p->pitch, 16, xO - 1, yO + y, &v)) { ip->left = 1; ip->pv[y + 1] = v; }
+    for (x = 0; x < 2 * n; x++) {
+        if (n == 4 && x > 3 && (blk == 3 || blk == 11)) continue; /* :412 */
+        if (neigh_sample(p, p->y, p->pitch, 16, xO + x, yO - 1, &v)) {
+            if (x < n) ip->up = 1; else ip->up_right = 1;
+            ip->ph[x + 1] = v;
+        }
+    }
+    if (ip->up && !ip->up_right) { /* :431-439, :1230-1236 */
+        for (x = n; x < 2 * n; x++) ip->ph[x + 1] = ip->ph[n];
+        ip->up_right = 1;
+    }
+}
+
+/* Within one macroblock, samples of the current MB that are later in decoding
+ * order must read as unavailable for Intra 8x8 block 3 (xN > 15 is caught by
+ * geometry) -- nothing else to do: 8x8 block 2's up-right is block 1 (already
+ * decoded) and the reference applies no blkIdx special case (:1210-1211). */
+
+/* ---- luma 8x8 prediction (h264_intra_prediction.c:1107-1800) ------------ */
+
+/* Intra_8x8_sample_filtering, :1295-1353 */
+static void filter8x8(const edge_t *ip, edge_t *f)
+{
+    int x, y;
+    memset(f, 0, sizeof(*f));
+    f->left = ip->left; f->up = ip->up; f->up_left = ip->up_left; f->up_right = ip->up_right;
+    if (ip->up && ip->up_right) {
+        if (ip->up_left) f->ph[1] = (ip->pv[0] + 2 * ip->ph[1] + ip->ph[2] + 2) >> 2;
+        else f->ph[1] = (3 * ip->ph[1] + ip->ph[2] + 2) >> 2;
+        for (x = 1; x < 15; x++)
+            f->ph[x + 1] = (ip->ph[x] + 2 * ip->ph[x + 1] + ip->ph[x + 2] + 2) >> 2;
+        f->ph[16] = (ip->ph[15] + 3 * ip->ph[16] + 2) >> 2;
+    }
+    if (ip->up_left) {
+        if (!ip->up || !ip->left) {
+            if (ip->up) f->pv[0] = f->ph[0] = (3 * ip->pv[0] + ip->ph[1] + 2) >> 2;
+            else if (!ip->up && ip->left) f->pv[0] = f->ph[0] = (3 * ip->pv[0] + ip->pv[1] + 2) >> 2;
+            else f->pv[0] = f->ph[0] = ip->pv[0];
+        } else
+            f->pv[0] = f->ph[0] = (ip->ph[1] + 2 * ip->pv[0] + ip->pv[1] + 2) >> 2;
+    }
+    if (ip->left) {
+        if (ip->up_left) f->pv[1] = (ip->pv[0] + 2 * ip->pv[1] + ip->pv[2] + 2) >> 2;
+        else f->pv[1] = (3 * ip->pv[1] + ip->pv[2] + 2) >> 2;
+        for (y = 1; y < 7; y++)
+            f->pv[y + 1] = (ip->pv[y] + 2 * ip->pv[y + 1] + ip->pv[y + 2] + 2) >> 2;
+        f->pv[8] = (ip->pv[7] + 3 * ip->pv[8] + 2) >> 2;
+    }
+}
+
+static void pred8x8(const edge_t *ip, int mode, int pred[8][8] /* [x][y] */)
+{
+    int x, y, i;
+    memset(pred, 0, 64 * sizeof(int));
+    switch (mode) {
+    case 0:
+        if (ip->up) for (x = 0; x < 8; x++) for (y = 0; y < 8; y++) pred[x][y] = ip->ph[x + 1];
+        break;
+    case 1:
+        if (ip->left) for (x = 0; x < 8; x++) for (y = 0; y < 8; y++) pred[x][y] = ip->pv[y + 1];
+        break;
+    case 2: {
+        int sumH = 0, sumV = 0, v;
+        for (i = 1; i <= 8; i++) { sumH += ip->ph[i]; sumV += ip->pv[i]; }
+        if (ip->up && ip->left) v = (sumH + sumV + 8) >> 4;
+        else if (ip->left) v = (sumV + 4) >> 3;
+        else if (ip->up) v = (sumH + 4) >> 3;
+        else v = 128;
+        for (x = 0; x < 8; x++) for (y = 0; y < 8; y++) pred[x][y] = v;
+        break;
+    }
+    case 3:
+        if (ip->up && ip->up_right)
+            for (x = 0; x < 8; x++) for (y = 0; y < 8; y++) {
+                if (x == 7 && y == 7) pred[x][y] = (ip->ph[15] + 3 * ip->ph[16] + 2) >> 2;
+                else pred[x][y] = (ip->ph[x + y + 1] + 2 * ip->ph[x + y + 2] + ip->ph[x + y + 3] + 2) >> 2;
+            }
+        break;
+    case 4:
+        if (ip->left && ip->up_left && ip->up)
+            for (x = 0; x < 8; x++) for (y = 0; y < 8; y++) {
+                if (x > y) pred[x][y] = (ip->ph[x - y - 1] + 2 * ip->ph[x - y] + ip->ph[x - y + 1] + 2) >> 2;
+                else if (x < y) pred[x][y] = (ip->pv[y - x - 1] + 2 * ip->pv[y - x] + ip->pv[y - x + 1] + 2) >> 2;
+                else pred[x][y] = (ip->ph[1] + 2 * ip->pv[0] + ip->pv[1] + 2) >> 2;
+            }
+        break;
+    case 5:
+        if (ip->left && ip->up_left && ip->up)
+            for (x = 0; x < 8; x++) for (y = 0; y < 8; y++) {
+                int z = 2 * x - y;
+                if (z > -1) {
+                    if (z % 2 == 0) pred[x][y] = (ip->ph[x - (y >> 1)] + ip->ph[x - (y >> 1) + 1] + 1) >> 1;
+                    else pred[x][y] = (ip->ph[x - (y >> 1) - 1] + 2 * ip->ph[x - (y >> 1)] + ip->ph[x - (y >> 1) + 1] + 2) >> 2;
+                } else if (z == -1) pred[x][y] = (ip->pv[1] + 2 * ip->pv[0] + ip->ph[1] + 2) >> 2;
+                else pred[x][y] = (ip->pv[y - 2 * x] + 2 * ip->pv[y - 2 * x - 1] + ip->pv[y - 2 * x - 2] + 2) >> 2;
+            }
+        break;
+    case 6:
+        if (ip->left && ip->up_left && ip->up)
+            for (x = 0; x < 8; x++) for (y = 0; y < 8; y++) {
+                int z = 2 * y - x;
+                if (z > -1) {
+                    if (z % 2 == 0) pred[x][y] = (ip->pv[y - (x >> 1)] + ip->pv[y - (x >> 1) + 1] + 1) >> 1;
+                    else pred[x][y] = (ip->pv[y - (x >> 1) - 1] + 2 * ip->pv[y - (x >> 1)] + ip->pv[y - (x >> 1) + 1] + 2) >> 2;
+                } else if (z == -1) pred[x][y] = (ip->pv[1] + 2 * ip->pv[0] + ip->ph[1] + 2) >> 2;
+                else pred[x][y] = (ip->ph[x - 2 * y] + 2 * ip->ph[x - 2 * y - 1] + ip->ph[x - 2 * y - 2] + 2) >> 2;
+            }
+        break;
+    case 7:
+        if (ip->up && ip->up_right)
+            for (x = 0; x < 8; x++) for (y = 0; y < 8; y++) {
+                if (y % 2 == 0) pred[x][y] = (ip->ph[x + (y >> 1) + 1] + ip->ph[x + (y >> 1) + 2] + 1) >> 1;
+                else pred[x][y] = (ip->ph[x + (y >> 1) + 1] + 2 * ip->ph[x + (y >> 1) + 2] + ip->ph[x + (y >> 1) + 3] + 2) >> 2;
+            }
+        break;
+    case 8:
+        if (ip->left)
+            for (x = 0; x < 8; x++) for (y = 0; y < 8; y++) {
+                int z = x + 2 * y;
+                if (z < 13) {
+                    if (z % 2 == 0) pred[x][y] = (ip->pv[y + (x >> 1) + 1] + ip->pv[y + (x >> 1) + 2] + 1) >> 1;
+                    else pred[x][y] = (ip->pv[y + (x >> 1) + 1] + 2 * ip->pv[y + (x >> 1) + 2] + ip->pv[y + (x >> 1) + 3] + 2) >> 2;
+                } else if (z == 13) pred[x][y] = (ip->pv[7] + 3 * ip->pv[8] + 2) >> 2;
+                else pred[x][y] = ip->pv[8];
+            }
+        break;
+    default:
+        break;
+    }
+}
+
+/* ---- macroblock reconstruction ------------------------------------------ */
+
+static void load_c4(const int16_t *src, int c[4][4])
+{
+    int i, j;
+    for (i = 0; i < 4; i++) for (j = 0; j < 4; j++) c[i][j] = src[i * 4 + j];
+}
+
+/* Intra_4x4_luma_prediction_process :161-177 + transform4x4_luma (h264_transform.c:121-156) */
+static void recon_i4x4(pic_t *p, const mvhp_mb_header_t *h, const int16_t *coef)
+{
+    int blk, x, y;
+    for (blk = 0; blk < 16; blk++) {
+        int xO, yO, c[4][4], r[4][4], pred[4][4];
+        edge_t ip;
+        blk4_xy(blk, &xO, &yO);
+        fetch_edges(p, xO, yO, 4, blk, &ip);
+        pred4x4(&ip, h->pred_mode[blk], pred);
+        load_c4(coef + blk * 16, c);
+        residual4x4(c, h->qp_y, 0, r);
+        for (y = 0; y < 4; y++)
+            for (x = 0; x < 4; x++)
+                p->y[(size_t)(p->mby * 16 + yO + y) * p->pitch + p->mbx * 16 + xO + x] =
+                    (uint8_t)clip255(pred[x][y] + r[y][x]);
+    }
+}
+
+/* Intra_8x8_luma_prediction_process :960-975 + transform8x8_luma (h264_transform.c:236-271) */
+static void recon_i8x8(pic_t *p, const mvhp_mb_header_t *h, const int16_t *coef)
+{
+    int blk, x, y, i, j;
+    for (blk = 0; blk < 4; blk++) {
+        int xO = (blk % 2) * 8, yO = (blk / 2) * 8;
+        int c[8][8], r[8][8], pred[8][8];
+        edge_t ip, f;
+        fetch_edges(p, xO, yO, 8, blk, &ip);
+        filter8x8(&ip, &f);
+        pred8x8(&f, h->pred_mode[blk], pred);
+        for (i = 0; i < 8; i++) for (j = 0; j < 8; j++) c[i][j] = coef[blk * 64 + i * 8 + j];
+        residual8x8(c, h->qp_y, r);
+        for (y = 0; y < 8; y++)
+            for (x = 0; x < 8; x++)
+                p->y[(size_t)(p->mby * 16 + yO + y) * p->pitch + p->mbx * 16 + xO + x] =
+                    (uint8_t)clip255(pred[x][y] + r[y][x]);
+    }
+}
+
+/* Intra_16x16_luma_prediction_process :1809-2141 + transform16x16_luma (h264_transform.c:168-223) */
+static void recon_i16x16(pic_t *p, const mvhp_mb_header_t *h, const int16_t *coef)
+{
+    int pv[16] = {0}, ph[16] = {0}, phv = 0, left = 0, up = 0, v, x, y, i, blk;
+    int pred[16][16]; /* [x][y] */
+    int rMb[16][16];  /* [x][y] */
+    int c1[4][4], dcY[4][4];
+    memset(pred, 0, sizeof(pred));
+    if (neigh_sample(p, p->y, p->pitch, 16, -1, -1, &v)) phv = v;
+    for (y = 0; y < 16; y++) if (neigh_sample(p, p->y, p->pitch, 16, -1, y, &v)) { left = 1; pv[y] = v; }
+    for (x = 0; x < 16; x++) if (neigh_sample(p, p->y, p->pitch, 16, x, -1, &v)) { up = 1; ph[x] = v; }
+    switch (h->i16_pred_mode) {
+    case 0:
+        if (up) for (x = 0; x < 16; x++) for (y = 0; y < 16; y++) pred[x][y] = ph[x];
+        break;
+    case 1:
+        if (left) for (x = 0; x < 16; x++) for (y = 0; y < 16; y++) pred[x][y] = pv[y];
+        break;
+    case 2: {
+        int sumH = 0, sumV = 0;
+        for (i = 0; i < 16; i++) { sumH += ph[i]; sumV += pv[i]; }
+        if (left && up) v = (sumH + sumV + 16) >> 5;
+        else if (left) v = (sumV + 8) >> 4;
+        else if (up) v = (sumH + 8) >> 4;
+        else v = 128;
+        for (x = 0; x < 16; x++) for (y = 0; y < 16; y++) pred[x][y] = v;
+        break;
+    }
+    case 3:
+        if (left && up) {
+            int H = 0, V = 0, a, b, c;
+            for (i = 0; i < 8; i++) {
+                if (6 - i == -1) { H += (i + 1) * (ph[8 + i] - phv); V += (i + 1) * (pv[8 + i] - phv); }
+                else { H += (i + 1) * (ph[8 + i] - ph[6 - i]); V += (i + 1) * (pv[8 + i] - pv[6 - i]); }
+            }
+            a = 16 * (pv[15] + ph[15]);
+            b = (5 * H + 32) >> 6;
+            c = (5 * V + 32) >> 6;
+            for (x = 0; x < 16; x++) for (y = 0; y < 16; y++)
+                pred[x][y] = clip255((a + b * (x - 7) + c * (y - 7) + 16) >> 5);
+        }
+        break;
+    default:
+        break;
+    }
+    /* DC: c1[i][j] sits in slot 0 of the block at raster position (i,j) */
+    for (blk = 0; blk < 16; blk++) {
+        int xO, yO;
+        blk4_xy(blk, &xO, &yO);
+        c1[yO / 4][xO / 4] = coef[blk * 16];
+    }
+    luma_dc(c1, h->qp_y, dcY);
+    for (blk = 0; blk < 16; blk++) {
+        int xO, yO, c[4][4], r[4][4];
+        blk4_xy(blk, &xO, &yO);
+        load_c4(coef + blk * 16, c);
+        c[0][0] = dcY[yO / 4][xO / 4];
+        residual4x4(c, h->qp_y, 1, r);
+        for (y = 0; y < 4; y++) for (x = 0; x < 4; x++) rMb[xO + x][yO + y] = r[y][x];
+    }
+    for (y = 0; y < 16; y++)
+        for (x = 0; x < 16; x++)
+            p->y[(size_t)(p->mby * 16 + y) * p->pitch + p->mbx * 16 + x] = (uint8_t)clip255(pred[x][y] + rMb[x][y]);
+}
+
+/* Intra_Chroma_prediction_process :2157-2564 + transform4x4_chroma (h264_transform.c:286-402) */
+static void recon_chroma(pic_t *p, const mvhp_mb_header_t *h, const int16_t *coef, int iCbCr)
+{
+    uint8_t *plane = iCbCr ? p->cr : p->cb;
+    int pv[9] = {0}, ph[9] = {0}, left = 0, up = 0, v, x, y, i, blk;
+    int pred[8][8]; /* [x][y] */
+    int rMb[8][8];  /* [x][y] */
+    int qPc = chroma_qp(h->qp_y, p->cqp_off[iCbCr]);
+    int cdc[4], dcC[4];
+    memset(pred, 0, sizeof(pred));
+    if (neigh_sample(p, plane, p->cpitch, 8, -1, -1, &v)) pv[0] = ph[0] = v;
+    for (y = 0; y < 8; y++) if (neigh_sample(p, plane, p->cpitch, 8, -1, y, &v)) { left = 1; pv[y + 1] = v; }
+    for (x = 0; x < 8; x++) if (neigh_sample(p, plane, p->cpitch, 8, x, -1, &v)) { up = 1; ph[x + 1] = v; }
+    switch (h->chroma_pred_mode) {
+    case 0: /* DC, :2338-2441 */
+        for (blk = 0; blk < 4; blk++) {
+            int xO = (blk % 2) * 4, yO = (blk / 2) * 4, sum = 0, have = 1;
+            if (!left && !up) v = 128;
+            else if ((xO == 0 && yO == 0) || (xO > 0 && yO > 0)) {
+                if (left && up) { for (i = 0; i < 4; i++) sum += ph[i + xO + 1] + pv[i + yO + 1]; v = (sum + 4) >> 3; }
+                else if (left) { for (i = 0; i < 4; i++) sum += pv[i + yO + 1]; v = (sum + 2) >> 2; }
+                else { for (i = 0; i < 4; i++) sum += ph[i + xO + 1]; v = (sum + 2) >> 2; }
+            } else if (xO > 0 && yO == 0) {
+                if (up) { for (i = 0; i < 4; i++) sum += ph[i + xO + 1]; v = (sum + 2) >> 2; }
+                else if (left) { for (i = 0; i < 4; i++) sum += pv[i + yO + 1]; v = (sum + 2) >> 2; }
+                else have = 0;
+            } else {
+                if (left) { for (i = 0; i < 4; i++) sum += pv[i + yO + 1]; v = (sum + 2) >> 2; }
+                else if (up) { for (i = 0; i < 4; i++) sum += ph[i + xO + 1]; v = (sum + 2) >> 2; }
+                else have = 0;
+            }
+            if (have) for (x = 0; x < 4; x++) for (y = 0; y < 4; y++) pred[x + xO][y + yO] = v;
+        }
+        break;
+    case 1:
+        if (left) for (x = 0; x < 8; x++) for (y = 0; y < 8; y++) pred[x][y] = pv[y + 1];
+        break;
+    case 2:
+        if (up) for (x = 0; x < 8; x++) for (y = 0; y < 8; y++) pred[x][y] = ph[x + 1];
+        break;
+    case 3:
+        if (left && up) {
+            int H = 0, V = 0, a, b, c;
+            for (i = 0; i < 4; i++) H += (i + 1) * (ph[4 + i + 1] - ph[2 - i + 1]);
+            for (i = 0; i < 4; i++) V += (i + 1) * (pv[4 + i + 1] - pv[2 - i + 1]);
+            a = 16 * (pv[8] + ph[8]);
+            b = (34 * H + 32) >> 6;
+            c = (34 * V + 32) >> 6;
+            for (x = 0; x < 8; x++) for (y = 0; y < 8; y++)
+                pred[x][y] = clip255((a + b * (x - 3) + c * (y - 3) + 16) >> 5);
+        }
+        break;
+    default:
+        break;
+    }
+    for (blk = 0; blk < 4; blk++) cdc[blk] = coef[blk * 16];
+    chroma_dc(cdc, qPc, dcC);
+    for (blk = 0; blk < 4; blk++) {
+        int xO = (blk % 2) * 4, yO = (blk / 2) * 4, c[4][4], r[4][4];
+        load_c4(coef + blk * 16, c);
+        c[0][0] = dcC[blk];
+        residual4x4(c, qPc, 1, r);
+        for (y = 0; y < 4; y++) for (x = 0; x < 4; x++) rMb[xO + x][yO + y] = r[y][x];
+    }
+    for (y = 0; y < 8; y++)
+        for (x = 0; x < 8; x++)
+            plane[(size_t)(p->mby * 8 + y) * p->cpitch + p->mbx * 8 + x] = (uint8_t)clip255(pred[x][y] + rMb[x][y]);
+}
+
+/* One picture: packed records -> planar Y|Cb|Cr (h264_slice.c:1046-1139 MB
+ * order; export.c:65-188 plane layout). Returns 1 on success. */
+ORC_EXPORT int orc_recon_frame(const mvhp_stream_params_t *sp, const void *packed, uint8_t *yuv)
+{
+    pic_t p;
+    int W = (int)sp->width_mbs, H = (int)sp->height_mbs, mb;
+    const uint8_t *base = (const uint8_t *)packed;
+    p.W = W; p.H = H; p.pitch = W * 16; p.cpitch = W * 8;
+    p.y = yuv;
+    p.cb = yuv + (size_t)W * 16 * H * 16;
+    p.cr = p.cb + (size_t)W * 8 * H * 8;
+    p.cqp_off[0] = sp->chroma_qp_index_offset;
+    p.cqp_off[1] = sp->second_chroma_qp_index_offset;
+    for (mb = 0; mb < W * H; mb++) {
+        mvhp_mb_header_t h;
+        int16_t coef[MVHP_MB_COEFS];
+        memcpy(&h, base + (size_t)mb * MVHP_MB_BYTES, sizeof(h));
+        memcpy(coef, base + (size_t)mb * MVHP_MB_BYTES + MVHP_MB_HEADER_BYTES, sizeof(coef));
+        p.mbx = mb % W; p.mby = mb / W;
+        if (h.mb_kind == MVHP_KIND_I4x4) recon_i4x4(&p, &h, coef);
+        else if (h.mb_kind == MVHP_KIND_I8x8) recon_i8x8(&p, &h, coef);
+        else if (h.mb_kind == MVHP_KIND_I16x16) recon_i16x16(&p, &h, coef);
+        else return 0;
+        recon_chroma(&p, &h, coef + 256, 0);
+        recon_chroma(&p, &h, coef + 320, 1);
+    }
+    return 1;
+}
+
+/* mb_to_rgb, export_utils.c:209-324: 2x2 nearest chroma replicate (:278-279),
+ * then the integer formula of :300-302. */
+ORC_EXPORT void orc_yuv_to_rgb(const mvhp_stream_params_t *sp, const uint8_t *yuv, uint8_t *rgb)
+{
+    int Wp = (int)sp->width_mbs * 16, Hp = (int)sp->height_mbs * 16, x, y;
+    const uint8_t *Y = yuv, *Cb = yuv + (size_t)Wp * Hp, *Cr = Cb + (size_t)(Wp / 2) * (Hp / 2);
+    for (y = 0; y < Hp; y++)
+        for (x = 0; x < Wp; x++) {
+            int l = Y[(size_t)y * Wp + x];
+            int cb = Cb[(size_t)(y / 2) * (Wp / 2) + x / 2];
+            int cr = Cr[(size_t)(y / 2) * (Wp / 2) + x / 2];
+            uint8_t *o = rgb + ((size_t)y * Wp + x) * 3;
+            o[0] = (uint8_t)clip255(((298 * l) >> 8) + ((408 * cr) >> 8) - 222);
+            o[1] = (uint8_t)clip255(((298 * l) >> 8) - ((100 * cb) >> 8) - ((208 * cr) >> 8) + 135);
+            o[2] = (uint8_t)clip255(((298 * l) >> 8) + ((516 * cb) >> 8) - 276);
+        }
+}
+
+/* Batch wrapper used by tests and by bench.py's cpu_baseline leg. */
+ORC_EXPORT int orc_recon_batch(const mvhp_stream_params_t *sp, const void *packed, int n_frames,
+                               uint8_t *yuv, uint8_t *rgb)
+{
+    size_t pb = (size_t)sp->width_mbs * sp->height_mbs * MVHP_MB_BYTES;
+    size_t yb = (size_t)sp->width_mbs * sp->height_mbs * 384;
+    int f;
+    for (f = 0; f < n_frames; f++) {
+        if (!orc_recon_frame(sp, (const uint8_t *)packed + f * pb, yuv + f * yb)) return 0;
+        if (rgb) orc_yuv_to_rgb(sp, yuv + f * yb, rgb + f * yb * 2);
+    }
+    return 1;
+}

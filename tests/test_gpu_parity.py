@@ -1,0 +1,105 @@
+"""GPU parity: hand-written HIP reconstruction (through the C-ABI) vs the CPU oracle, bit-exact."""
+import numpy as np
+import pytest
+
+from minivideo_amd.synth import synth_packed
+from oracle import loader
+from tests.kat import EXPECTED_Y, kat_packed
+
+pytestmark = pytest.mark.gpu
+
+
+def _check(hot, params, rec, n, want_rgb=True):
+    yuv_g, rgb_g = hot.recon_host(params, rec, n, want_rgb=want_rgb)
+    yuv_o, rgb_o = loader.recon(params, rec, n, want_rgb=want_rgb)
+    if not np.array_equal(yuv_g, yuv_o):
+        bad = np.nonzero(yuv_g != yuv_o)[0]
+        fb = params.yuv_bytes
+        f, off = divmod(int(bad[0]), fb)
+        raise AssertionError(f"{bad.size} YUV bytes differ; first at frame {f} offset {off} "
+                             f"(gpu {yuv_g[bad[0]]} oracle {yuv_o[bad[0]]})")
+    if want_rgb:
+        assert np.array_equal(rgb_g, rgb_o)
+
+
+@pytest.mark.parametrize("qp", sorted(EXPECTED_Y))
+def test_reference_kat_on_gpu(hot, qp):
+    params, rec = kat_packed(qp)
+    yuv, _ = hot.recon_host(params, rec, 1)
+    assert np.all(yuv[:512] == EXPECTED_Y[qp]) and np.all(yuv[512:] == 128)
+
+
+@pytest.mark.parametrize("W,H", [(1, 1), (2, 1), (1, 2), (3, 2), (5, 3), (11, 9), (20, 17), (64, 5), (7, 35)])
+@pytest.mark.parametrize("profile", ["baseline", "high"])
+def test_dense_small(hot, W, H, profile):
+    params, rec = synth_packed(W, H, 3, seed=W * 100 + H, profile=profile, density="dense")
+    _check(hot, params, rec, 3)
+
+
+@pytest.mark.parametrize("waves", [4, 8, 16])
+def test_waves_per_picture(hot, waves):
+    hot.set_waves_per_picture(waves)
+    try:
+        params, rec = synth_packed(23, 37, 5, seed=waves, profile="high", density="dense")
+        _check(hot, params, rec, 5)
+    finally:
+        hot.set_waves_per_picture(0)
+
+
+def test_light_content(hot):
+    params, rec = synth_packed(30, 20, 4, seed=5, density="light")
+    _check(hot, params, rec, 4)
+
+
+@pytest.mark.parametrize("qp_range", [(0, 12), (13, 23), (24, 35), (36, 51)])
+def test_qp_ranges(hot, qp_range):
+    params, rec = synth_packed(12, 7, 2, seed=qp_range[0], profile="high", qp_range=qp_range, cqp_offsets=(3, -5))
+    _check(hot, params, rec, 2)
+
+
+def test_chroma_qp_offsets_extremes(hot):
+    for off in [(-12, 12), (12, -12)]:
+        params, rec = synth_packed(9, 6, 2, seed=77, profile="high", qp_range=(0, 51), cqp_offsets=off)
+        _check(hot, params, rec, 2)
+
+
+def test_unavailable_neighbour_modes_predict_zero(hot):
+    # modes whose neighbours are missing: the reference logs and predicts 0 (h264_intra_prediction.c:442)
+    params, rec = synth_packed(10, 6, 3, seed=9, profile="high", illegal_modes=True)
+    _check(hot, params, rec, 3)
+
+
+def test_qp36_intra16x16_defect(hot):
+    params, rec = synth_packed(10, 6, 2, seed=10, qp_range=(36, 36), allow_qp36_i16=True)
+    _check(hot, params, rec, 2)
+
+
+def test_large_levels(hot):
+    params, rec = synth_packed(8, 8, 2, seed=11, profile="high", qp_range=(0, 51))
+    coef = rec[..., 32:].view(np.int16)
+    big = np.random.default_rng(3).integers(-2000, 2000, size=coef.shape).astype(np.int16)
+    mask = np.random.default_rng(4).random(coef.shape) < 0.05
+    coef[mask] = big[mask]
+    rec[..., 8:12] = np.array([0xFFFFFF], np.uint32).view(np.uint8)
+    _check(hot, params, rec, 2)
+
+
+def test_full_hd_frames(hot):
+    params, rec = synth_packed(120, 68, 2, seed=1080, profile="baseline", density="dense")
+    _check(hot, params, rec, 2)
+
+
+def test_4k_frame_high(hot):
+    params, rec = synth_packed(240, 135, 1, seed=2160, profile="high", density="dense")
+    _check(hot, params, rec, 1)
+
+
+def test_idempotent_and_frame_independent(hot):
+    # frames are independent units: reconstructing a sub-batch gives the same pictures
+    params, rec = synth_packed(40, 30, 6, seed=21, profile="high")
+    yuv_all, _ = hot.recon_host(params, rec, 6)
+    yuv_sub, _ = hot.recon_host(params, rec[2:5], 3)
+    fb = params.yuv_bytes
+    assert np.array_equal(yuv_all[2 * fb:5 * fb], yuv_sub)
+    yuv_again, _ = hot.recon_host(params, rec, 6)
+    assert np.array_equal(yuv_all, yuv_again)
