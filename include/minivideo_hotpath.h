@@ -135,6 +135,14 @@ MVHP_EXPORT int  mvhp_recon_batch_dev(mvhp_ctx_t *ctx, const mvhp_stream_params_
                                       const void *d_packed, int n_frames,
                                       uint8_t *d_yuv, uint8_t *d_rgb, void *stream);
 
+/* Same, but only the stages selected by `stages` (bit 0: reconstruction kernel,
+ * bit 1: colour kernel) -- lets a caller bracket each kernel with its own events. */
+#define MVHP_STAGE_RECON 1
+#define MVHP_STAGE_COLOR 2
+MVHP_EXPORT int  mvhp_recon_stages_dev(mvhp_ctx_t *ctx, const mvhp_stream_params_t *p,
+                                       const void *d_packed, int n_frames,
+                                       uint8_t *d_yuv, uint8_t *d_rgb, void *stream, int stages);
+
 /* Wait for `stream` (NULL = context stream) and report any error the kernels
  * flagged since the last check. */
 MVHP_EXPORT int  mvhp_sync_check(mvhp_ctx_t *ctx, void *stream);

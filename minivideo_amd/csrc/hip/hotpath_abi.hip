@@ -188,6 +188,18 @@ MVHP_EXPORT int mvhp_recon_batch_dev(mvhp_ctx_t *c, const mvhp_stream_params_t *
     return launch_all(c, p, d_packed, n_frames, d_yuv, d_rgb, st, true, true);
 }
 
+MVHP_EXPORT int mvhp_recon_stages_dev(mvhp_ctx_t *c, const mvhp_stream_params_t *p, const void *d_packed,
+                                      int n_frames, uint8_t *d_yuv, uint8_t *d_rgb, void *stream, int stages)
+{
+    if (!c || !params_ok(p) || !d_packed || !d_yuv || n_frames <= 0 || (stages & ~3) || !stages) {
+        set_err("mvhp_recon_stages_dev: invalid argument");
+        return MVHP_FAILURE;
+    }
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+    return launch_all(c, p, d_packed, n_frames, d_yuv, d_rgb, st, (stages & 1) != 0, (stages & 2) != 0);
+}
+
 static int ensure(void **ptr, size_t *have, size_t need)
 {
     if (*have >= need) return MVHP_SUCCESS;

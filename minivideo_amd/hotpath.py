@@ -73,6 +73,8 @@ def lib():
     L.mvhp_set_waves_per_picture.argtypes = [vp, i32]
     L.mvhp_recon_batch_dev.restype = i32
     L.mvhp_recon_batch_dev.argtypes = [vp, pp, vp, i32, vp, vp, vp]
+    L.mvhp_recon_stages_dev.restype = i32
+    L.mvhp_recon_stages_dev.argtypes = [vp, pp, vp, i32, vp, vp, vp, i32]
     L.mvhp_recon_batch_host.restype = i32
     L.mvhp_recon_batch_host.argtypes = [vp, pp, vp, i32, vp, vp]
     L.mvhp_sync_check.restype = i32
@@ -145,6 +147,12 @@ class HotPath:
         rc = self._L.mvhp_recon_batch_dev(self._h, C.byref(params), d_packed, int(n_frames), d_yuv, d_rgb, stream)
         if rc != SUCCESS:
             raise _err(self._L, "mvhp_recon_batch_dev")
+
+    def recon_stages_dev(self, params, d_packed, n_frames, d_yuv, d_rgb, stream, stages):
+        rc = self._L.mvhp_recon_stages_dev(self._h, C.byref(params), d_packed, int(n_frames), d_yuv, d_rgb,
+                                           stream, int(stages))
+        if rc != SUCCESS:
+            raise _err(self._L, "mvhp_recon_stages_dev")
 
     def sync_check(self, stream=None):
         if self._L.mvhp_sync_check(self._h, stream) != SUCCESS:
