@@ -116,6 +116,7 @@ MVHP_EXPORT int  mvhp_stream_params(const mvhp_stream_t *s, int idr, mvhp_stream
 /* Entropy-decode IDR picture `idr` into `packed` (mvhp_packed_frame_bytes()).
  * Thread-safe for distinct `idr` on the same handle. */
 MVHP_EXPORT int  mvhp_stream_decode_packed(const mvhp_stream_t *s, int idr, void *packed, size_t packed_bytes);
+MVHP_EXPORT const char *mvhp_stream_last_error(void);
 
 /* ---------------------------------------------------------------------------
  * GPU reconstruction.

@@ -1,0 +1,649 @@
+// h264_frontend.cpp -- see h264_frontend.h for the reference functions restated here.
+#include "h264_frontend.h"
+
+#include <stdlib.h>
+#include <string.h>
+
+#include "h264_cabac.h"
+#include "h264_tables.h"
+
+namespace h264 {
+
+// ---------------------------------------------------------------------------
+// H1: Annex-B elementary-stream index (esparser.c:40-143)
+// ---------------------------------------------------------------------------
+int index_annexb(const uint8_t *data, size_t size, std::vector<EsSample> &out)
+{
+    out.clear();
+    if (!data) return RC_FAILURE;
+    const int64_t limit = (int64_t)size - 32; // esparser.c:65: the scan stops 32 bytes before EOF
+    int64_t off = 0;
+    int zeros = 0;
+    while (off < limit) {
+        const uint8_t b = data[off++];
+        if (b == 0x00) {
+            zeros++;
+        } else {
+            if (b == 0x01 && zeros > 2) { // needs >= 3 zero bytes (esparser.c:78)
+                const uint8_t nb = data[off];
+                if (nb == 0x65 || nb == 0x67 || nb == 0x68) { // esparser.c:82
+                    EsSample s;
+                    s.offset = (size_t)off;
+                    s.nal_unit_type = nb & 31;
+                    s.nal_ref_idc = (nb >> 5) & 3;
+                    s.is_idr = (nb == 0x65);
+                    if (!out.empty()) out.back().sample_size = s.offset - out.back().offset;
+                    out.push_back(s);
+                }
+            }
+            zeros = 0;
+        }
+    }
+    if (out.empty()) return RC_FAILURE;
+    out.back().sample_size = size - out.back().offset;
+    // true NAL extent: up to the next start code prefix, trailing zero bytes trimmed
+    for (size_t i = 0; i < out.size(); i++) {
+        const size_t beg = out[i].offset, lim = beg + out[i].sample_size;
+        size_t end = lim;
+        for (size_t p = beg + 1; p + 2 < lim; p++) {
+            if (data[p] == 0 && data[p + 1] == 0 && data[p + 2] == 1) { end = p; break; }
+        }
+        while (end > beg + 1 && data[end - 1] == 0) end--;
+        out[i].nal_size = end - beg;
+    }
+    return RC_SUCCESS;
+}
+
+// H4: emulation prevention removal (h264_nalu.c:195-249)
+void unescape_rbsp(const uint8_t *src, size_t n, std::vector<uint8_t> &dst)
+{
+    dst.clear();
+    dst.reserve(n);
+    int zeros = 0;
+    for (size_t i = 0; i < n; i++) {
+        const uint8_t b = src[i];
+        if (zeros >= 2 && b == 0x03) { zeros = 0; continue; }
+        dst.push_back(b);
+        zeros = (b == 0) ? zeros + 1 : 0;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// H5: parameter sets
+// ---------------------------------------------------------------------------
+static bool is_frext_profile(int p)
+{
+    return p == 100 || p == 110 || p == 122 || p == 244 || p == 44 || p == 83 || p == 86 || p == 118 || p == 128;
+}
+
+int parse_sps(BitReader &br, Sps &s, std::string &err)
+{
+    s = Sps();
+    s.profile_idc = (int)br.bits(8);
+    br.bits(6);                                   // constraint_set0..5
+    if (br.bits(2) != 0) { err = "SPS: reserved_zero_2bits != 0"; return RC_FAILURE; }
+    s.level_idc = (int)br.bits(8);
+    s.sps_id = (int)br.ue();
+    if (s.sps_id > 31) { err = "SPS: seq_parameter_set_id out of range"; return RC_FAILURE; }
+    if (is_frext_profile(s.profile_idc)) {
+        s.chroma_format_idc = (int)br.ue();
+        if (s.chroma_format_idc != 1) { err = "SPS: only 4:2:0 is supported"; return RC_UNSUPPORTED; } // :175-199
+        const unsigned bdl = br.ue(), bdc = br.ue();
+        if (bdl != 0 || bdc != 0) { err = "SPS: only 8-bit samples are supported"; return RC_UNSUPPORTED; }
+        s.qpprime_y_zero_transform_bypass = br.bit();
+        if (br.bit()) { err = "SPS: scaling matrices are not supported"; return RC_UNSUPPORTED; } // SURVEY 8b envelope
+    }
+    // h264_parameterset.c:458-465: only Baseline(66), Main(77), High(100)
+    if (s.profile_idc != 66 && s.profile_idc != 77 && s.profile_idc != 100) {
+        err = "SPS: unsupported profile_idc";
+        return RC_UNSUPPORTED;
+    }
+    s.log2_max_frame_num = (int)br.ue() + 4;
+    if (s.log2_max_frame_num > 16) { err = "SPS: log2_max_frame_num_minus4 out of range"; return RC_FAILURE; }
+    s.poc_type = (int)br.ue();
+    if (s.poc_type == 0) {
+        s.log2_max_poc_lsb = (int)br.ue() + 4;
+        if (s.log2_max_poc_lsb > 16) { err = "SPS: log2_max_pic_order_cnt_lsb_minus4 out of range"; return RC_FAILURE; }
+    } else if (s.poc_type == 1) {
+        s.delta_pic_order_always_zero = br.bit();
+        br.se();
+        br.se();
+        const unsigned n = br.ue();
+        if (n > 255) { err = "SPS: num_ref_frames_in_pic_order_cnt_cycle out of range"; return RC_FAILURE; }
+        for (unsigned i = 0; i < n; i++) br.se();
+    } else if (s.poc_type > 2) {
+        err = "SPS: pic_order_cnt_type out of range";
+        return RC_FAILURE;
+    }
+    br.ue();  // max_num_ref_frames
+    br.bit(); // gaps_in_frame_num_value_allowed_flag
+    s.width_mbs = (int)br.ue() + 1;
+    s.height_map_units = (int)br.ue() + 1;
+    s.frame_mbs_only = br.bit();
+    if (!s.frame_mbs_only) { err = "SPS: interlaced streams are not supported"; return RC_UNSUPPORTED; }
+    s.direct_8x8_inference = br.bit();
+    s.frame_cropping = br.bit();
+    if (s.frame_cropping)
+        for (int i = 0; i < 4; i++) s.crop[i] = (int)br.ue(); // parsed, never applied (export.c:80-81)
+    br.bit(); // vui_parameters_present_flag: VUI is parse-and-ignore in the reference; nothing after it matters
+    if (br.overrun()) { err = "SPS: truncated"; return RC_FAILURE; }
+    if (s.width_mbs <= 0 || s.height_map_units <= 0 || s.width_mbs > 1024 || s.height_map_units > 1024) {
+        err = "SPS: picture size out of range";
+        return RC_FAILURE;
+    }
+    s.valid = true;
+    return RC_SUCCESS;
+}
+
+int parse_pps(BitReader &br, const Sps *sps_table, Pps &p, std::string &err)
+{
+    p = Pps();
+    p.pps_id = (int)br.ue();
+    p.sps_id = (int)br.ue();
+    if (p.pps_id > 255 || p.sps_id > 31) { err = "PPS: id out of range"; return RC_FAILURE; }
+    p.entropy_coding_mode = br.bit();
+    p.bottom_field_pic_order_in_frame_present = br.bit();
+    p.num_slice_groups_minus1 = (int)br.ue();
+    if (p.num_slice_groups_minus1 > 0) { err = "PPS: slice groups (FMO) are not supported"; return RC_UNSUPPORTED; }
+    br.ue(); // num_ref_idx_l0_default_active_minus1
+    br.ue(); // num_ref_idx_l1_default_active_minus1
+    p.weighted_pred = br.bit();
+    p.weighted_bipred_idc = (int)br.bits(2);
+    p.pic_init_qp_minus26 = br.se();
+    p.pic_init_qs_minus26 = br.se();
+    p.chroma_qp_index_offset = br.se();
+    p.deblocking_filter_control_present = br.bit();
+    p.constrained_intra_pred = br.bit();
+    p.redundant_pic_cnt_present = br.bit();
+    const Sps &s = sps_table[p.sps_id];
+    if (!s.valid) { err = "PPS: refers to an SPS that was not received"; return RC_FAILURE; }
+    // h264_parameterset.c:898: extension read when more_rbsp_data() && profile_idc >= 100
+    if (br.more_rbsp_data() && s.profile_idc >= 100) {
+        p.transform_8x8_mode = br.bit();
+        if (br.bit()) { err = "PPS: scaling matrices are not supported"; return RC_UNSUPPORTED; } // :904-923
+        p.second_chroma_qp_index_offset = br.se();
+    } else {
+        p.second_chroma_qp_index_offset = p.chroma_qp_index_offset;
+    }
+    if (br.overrun()) { err = "PPS: truncated"; return RC_FAILURE; }
+    if (p.chroma_qp_index_offset < -12 || p.chroma_qp_index_offset > 12 || p.second_chroma_qp_index_offset < -12 ||
+        p.second_chroma_qp_index_offset > 12 || p.pic_init_qp_minus26 < -26 || p.pic_init_qp_minus26 > 25) {
+        err = "PPS: QP parameters out of range";
+        return RC_FAILURE;
+    }
+    p.valid = true;
+    return RC_SUCCESS;
+}
+
+// ---------------------------------------------------------------------------
+// picture decoder
+// ---------------------------------------------------------------------------
+PictureDecoder::PictureDecoder(const Sps &sps, const Pps &pps, int nal_ref_idc)
+    : sps_(sps), pps_(pps), nal_ref_idc_(nal_ref_idc), W_(sps.width_mbs), H_(sps.height_map_units)
+{
+}
+
+PictureDecoder::~PictureDecoder() { delete cabac_; }
+
+int PictureDecoder::decode(const uint8_t *rbsp, size_t n, uint8_t *packed, size_t packed_bytes, std::string &err)
+{
+    if ((size_t)W_ * H_ * MVHP_MB_BYTES != packed_bytes) { err = "packed buffer size mismatch"; return RC_FAILURE; }
+    br_ = BitReader(rbsp, n);
+    out_ = packed;
+    memset(out_, 0, packed_bytes);
+    mbs_.assign((size_t)W_ * H_, MbState());
+    level_overflow_ = false;
+    int rc = slice_header(err);
+    if (rc != RC_SUCCESS) return rc;
+    rc = slice_data(err);
+    if (rc != RC_SUCCESS) return rc;
+    if (level_overflow_) { err = "transform coefficient level outside int16"; return RC_FAILURE; }
+    return RC_SUCCESS;
+}
+
+// H6: decodeSliceHeader, h264_slice.c:156-334 (IDR / I slices only)
+int PictureDecoder::slice_header(std::string &err)
+{
+    br_.ue();                                  // first_mb_in_slice: ignored, the MB loop starts at 0 (:1019)
+    const unsigned slice_type = br_.ue();
+    br_.ue();                                  // pic_parameter_set_id (resolved by the caller)
+    if (slice_type != 2 && slice_type != 7) { err = "slice: IDR slice_type must be I (2 or 7)"; return RC_FAILURE; }
+    const unsigned frame_num = br_.bits(sps_.log2_max_frame_num);
+    if (frame_num != 0) { err = "slice: IDR frame_num must be 0"; return RC_FAILURE; } // checkSliceHeader :531-537
+    const unsigned idr_pic_id = br_.ue();
+    if (idr_pic_id > 65535) { err = "slice: idr_pic_id out of range"; return RC_FAILURE; }
+    if (sps_.poc_type == 0) {
+        br_.bits(sps_.log2_max_poc_lsb);
+        if (pps_.bottom_field_pic_order_in_frame_present) br_.se();
+    } else if (sps_.poc_type == 1 && !sps_.delta_pic_order_always_zero) {
+        br_.se();
+        if (pps_.bottom_field_pic_order_in_frame_present) br_.se();
+    }
+    if (pps_.redundant_pic_cnt_present) br_.ue();
+    if (nal_ref_idc_ != 0) { // dec_ref_pic_marking() of an IDR picture (:863-867)
+        br_.bit();
+        br_.bit();
+    }
+    const int slice_qp_delta = br_.se();
+    slice_qp_ = 26 + pps_.pic_init_qp_minus26 + slice_qp_delta; // :293
+    qp_prev_ = slice_qp_;
+    if (slice_qp_ < 0 || slice_qp_ > 51) { err = "slice: SliceQPY out of range"; return RC_FAILURE; }
+    if (pps_.deblocking_filter_control_present) {
+        const unsigned idc = br_.ue();         // parsed and ignored: the reference never deblocks
+        if (idc != 1) { br_.se(); br_.se(); }
+    }
+    if (br_.overrun()) { err = "slice header truncated"; return RC_FAILURE; }
+    return RC_SUCCESS;
+}
+
+// decodeSliceData, h264_slice.c:1013-1142
+int PictureDecoder::slice_data(std::string &err)
+{
+    const int n_mbs = W_ * H_;
+    if (pps_.entropy_coding_mode) {
+        while (!br_.byte_aligned()) {
+            if (br_.bit() == 0) { err = "slice: cabac_alignment_one_bit is 0"; return RC_FAILURE; }
+        }
+        delete cabac_;
+        cabac_ = new CabacEngine(*this);
+        cabac_->init(slice_qp_);
+    }
+    for (int addr = 0; addr < n_mbs; addr++) {
+        int rc = macroblock(addr, err);
+        if (rc != RC_SUCCESS) return rc;
+        if (pps_.entropy_coding_mode) {
+            const int end = cabac_->decode_terminate();
+            if (end) {
+                if (addr != n_mbs - 1) { err = "slice ends before the last macroblock (one slice per picture only)"; return RC_FAILURE; }
+                break;
+            }
+        }
+        if (br_.overrun()) { err = "slice data truncated"; return RC_FAILURE; }
+    }
+    return RC_SUCCESS;
+}
+
+// neighbouring 4x4 luma blocks (6.4.11.4 via h264_spatial.c:559): returns MB address or -1
+static inline int luma_neighbour_A(int addr, int W, int blk, int *blkN)
+{
+    const int x = blk4_x(blk), y = blk4_y(blk);
+    if (x > 0) { *blkN = blk4_from_xy(x - 4, y); return addr; }
+    *blkN = blk4_from_xy(12, y);
+    return (addr % W) > 0 ? addr - 1 : -1;
+}
+static inline int luma_neighbour_B(int addr, int W, int blk, int *blkN)
+{
+    const int x = blk4_x(blk), y = blk4_y(blk);
+    if (y > 0) { *blkN = blk4_from_xy(x, y - 4); return addr; }
+    *blkN = blk4_from_xy(x, 12);
+    return addr >= W ? addr - W : -1;
+}
+// neighbouring 4x4 chroma blocks, 4:2:0 (h264_spatial.c:631)
+static inline int chroma_neighbour_A(int addr, int W, int blk, int *blkN)
+{
+    if (blk & 1) { *blkN = blk - 1; return addr; }
+    *blkN = blk + 1;
+    return (addr % W) > 0 ? addr - 1 : -1;
+}
+static inline int chroma_neighbour_B(int addr, int W, int blk, int *blkN)
+{
+    if (blk & 2) { *blkN = blk - 2; return addr; }
+    *blkN = blk + 2;
+    return addr >= W ? addr - W : -1;
+}
+
+// G1: Intra_4x4_deriv_PredMode (h264_intra_prediction.c:196-290) and
+// Intra_8x8_deriv_PredMode (:977-1083), constrained_intra_pred irrelevant in I pictures.
+void PictureDecoder::derive_pred_modes(int addr, const uint8_t prev_flag[16], const uint8_t rem[16])
+{
+    MbState &mb = mbs_[addr];
+    if (mb.kind == MVHP_KIND_I4x4) {
+        for (int blk = 0; blk < 16; blk++) {
+            int bA, bB;
+            const int aA = luma_neighbour_A(addr, W_, blk, &bA), aB = luma_neighbour_B(addr, W_, blk, &bB);
+            int mA = 2, mB = 2;
+            if (aA >= 0 && aB >= 0) {
+                const MbState &A = mbs_[aA], &B = mbs_[aB];
+                if (A.kind == MVHP_KIND_I4x4) mA = A.pred[bA];
+                else if (A.kind == MVHP_KIND_I8x8) mA = A.pred[bA >> 2];
+                if (B.kind == MVHP_KIND_I4x4) mB = B.pred[bB];
+                else if (B.kind == MVHP_KIND_I8x8) mB = B.pred[bB >> 2];
+            }
+            const int pm = mA < mB ? mA : mB;
+            mb.pred[blk] = (uint8_t)(prev_flag[blk] ? pm : (rem[blk] < pm ? rem[blk] : rem[blk] + 1));
+        }
+    } else if (mb.kind == MVHP_KIND_I8x8) {
+        for (int blk = 0; blk < 4; blk++) {
+            // deriv_8x8lumablocks, h264_spatial.c:461
+            int aA, bA, aB, bB;
+            if (blk & 1) { aA = addr; bA = blk - 1; } else { aA = mbA(addr); bA = blk + 1; }
+            if (blk & 2) { aB = addr; bB = blk - 2; } else { aB = mbB(addr); bB = blk + 2; }
+            int mA = 2, mB = 2;
+            if (aA >= 0 && aB >= 0) {
+                const MbState &A = mbs_[aA], &B = mbs_[aB];
+                if (A.kind == MVHP_KIND_I8x8) mA = A.pred[bA];
+                else if (A.kind == MVHP_KIND_I4x4) mA = A.pred[bA * 4 + 1];
+                if (B.kind == MVHP_KIND_I8x8) mB = B.pred[bB];
+                else if (B.kind == MVHP_KIND_I4x4) mB = B.pred[bB * 4 + 2];
+            }
+            const int pm = mA < mB ? mA : mB;
+            mb.pred[blk] = (uint8_t)(prev_flag[blk] ? pm : (rem[blk] < pm ? rem[blk] : rem[blk] + 1));
+        }
+    }
+}
+
+// H7: macroblock_layer, h264_macroblock.c:75-313
+int PictureDecoder::macroblock(int addr, std::string &err)
+{
+    MbState &mb = mbs_[addr];
+    const bool cabac = pps_.entropy_coding_mode;
+    const unsigned mb_type = cabac ? cabac_->mb_type(addr) : br_.ue();
+    if (mb_type == 25) { err = "I_PCM macroblocks are not supported"; return RC_UNSUPPORTED; } // :151-154
+    if (mb_type > 25) { err = "invalid mb_type in an I slice"; return RC_FAILURE; }
+    mb.mb_type = (uint8_t)mb_type;
+    uint8_t prev_flag[16] = {0}, rem[16] = {0};
+    int i16_mode = 0;
+    if (mb_type == 0) {
+        mb.kind = MVHP_KIND_I4x4;
+        if (pps_.transform_8x8_mode) {
+            const int t8 = cabac ? cabac_->transform_size_8x8_flag(addr) : (int)br_.bit();
+            mb.transform8x8 = (uint8_t)t8;
+            if (t8) mb.kind = MVHP_KIND_I8x8;
+        }
+        const int n = (mb.kind == MVHP_KIND_I8x8) ? 4 : 16;
+        for (int b = 0; b < n; b++) { // mb_pred, :393-450
+            if (cabac) {
+                prev_flag[b] = (uint8_t)cabac_->prev_intra_pred_mode_flag();
+                if (!prev_flag[b]) rem[b] = (uint8_t)cabac_->rem_intra_pred_mode();
+            } else {
+                prev_flag[b] = (uint8_t)br_.bit();
+                if (!prev_flag[b]) rem[b] = (uint8_t)br_.bits(3);
+            }
+        }
+        derive_pred_modes(addr, prev_flag, rem);
+    } else {
+        // Table 7-11 (MbPartPredMode, :766-842)
+        mb.kind = MVHP_KIND_I16x16;
+        i16_mode = (int)(mb_type - 1) % 4;
+        mb.cbp_chroma = (uint8_t)(((mb_type - 1) / 4) % 3);
+        mb.cbp_luma = (mb_type > 12) ? 15 : 0;
+    }
+    {
+        const unsigned cm = cabac ? cabac_->intra_chroma_pred_mode(addr) : br_.ue();
+        if (cm > 3) { err = "intra_chroma_pred_mode out of range"; return RC_FAILURE; }
+        mb.chroma_pred_mode = (uint8_t)cm;
+    }
+    if (mb.kind != MVHP_KIND_I16x16) {
+        unsigned cbp;
+        if (cabac) cbp = cabac_->coded_block_pattern(addr);
+        else {
+            const unsigned code = br_.ue(); // me(v), h264_expgolomb.c:130, Table 9-4 intra column
+            if (code > 47) { err = "coded_block_pattern codeNum out of range"; return RC_FAILURE; }
+            cbp = kCbpIntraFromCodeNum[code];
+        }
+        mb.cbp_luma = (uint8_t)(cbp % 16);
+        mb.cbp_chroma = (uint8_t)(cbp / 16);
+    }
+    int mb_qp_delta = 0;
+    if (mb.cbp_luma > 0 || mb.cbp_chroma > 0 || mb.kind == MVHP_KIND_I16x16) {
+        mb_qp_delta = cabac ? cabac_->mb_qp_delta(addr) : br_.se();
+        mb.qp_delta_nonzero = mb_qp_delta != 0;
+        int rc = residual(addr, err);
+        if (rc != RC_SUCCESS) return rc;
+    }
+    // :263-269 (QpBdOffsetY = 0)
+    int qp = qp_prev_;
+    if (mb_qp_delta) qp = (qp_prev_ + mb_qp_delta + 52) % 52;
+    if (qp < 0 || qp > 51) { err = "mb_qp_delta out of range"; return RC_FAILURE; }
+    qp_prev_ = qp;
+
+    // header of the packed record
+    mvhp_mb_header_t h;
+    memset(&h, 0, sizeof(h));
+    h.mb_kind = mb.kind;
+    h.qp_y = (uint8_t)qp;
+    h.cbp = (uint8_t)(mb.cbp_luma | (mb.cbp_chroma << 4));
+    h.chroma_pred_mode = mb.chroma_pred_mode;
+    h.i16_pred_mode = (uint8_t)i16_mode;
+    memcpy(h.pred_mode, mb.pred, 16);
+    uint8_t *rec = out_ + (size_t)addr * MVHP_MB_BYTES;
+    const int16_t *coef = reinterpret_cast<const int16_t *>(rec + MVHP_MB_HEADER_BYTES);
+    uint32_t nz = 0;
+    for (int b = 0; b < 24; b++) {
+        bool any = false;
+        for (int i = 0; i < 16; i++) any |= coef[b * 16 + i] != 0;
+        if (any) nz |= 1u << b;
+    }
+    if (mb.kind == MVHP_KIND_I8x8)
+        for (int k = 0; k < 4; k++)
+            if (nz & (0xfu << (4 * k))) nz |= 0xfu << (4 * k);
+    h.nz_mask = nz;
+    memcpy(rec, &h, sizeof(h));
+    return RC_SUCCESS;
+}
+
+// inverse scan + placement of one decoded block into the packed record
+void PictureDecoder::scatter(int addr, int cat, int blkIdx, const int *coeff, int n)
+{
+    int16_t *coef = reinterpret_cast<int16_t *>(out_ + (size_t)addr * MVHP_MB_BYTES + MVHP_MB_HEADER_BYTES);
+    auto put = [&](int idx, int v) {
+        if (v > 32767 || v < -32768) { level_overflow_ = true; v = 0; }
+        coef[idx] = (int16_t)v;
+    };
+    switch (cat) {
+    case CAT_LUMA_8x8: // coeff[64] in 8x8 zig-zag order
+        for (int i = 0; i < n; i++) if (coeff[i]) put(blkIdx * 64 + kZigzag8x8[i], coeff[i]);
+        break;
+    case CAT_LUMA_4x4:
+        for (int i = 0; i < n; i++) if (coeff[i]) put(blkIdx * 16 + kZigzag4x4[i], coeff[i]);
+        break;
+    case CAT_LUMA_16x16_DC: // c1[row][col] -> slot 0 of the block at that raster position
+        for (int i = 0; i < n; i++)
+            if (coeff[i]) {
+                const int rc = kZigzag4x4[i];
+                put(blk4_from_xy((rc & 3) * 4, (rc >> 2) * 4) * 16, coeff[i]);
+            }
+        break;
+    case CAT_LUMA_16x16_AC: // coeff[k] is zig-zag position k+1
+        for (int i = 0; i < n; i++) if (coeff[i]) put(blkIdx * 16 + kZigzag4x4[i + 1], coeff[i]);
+        break;
+    case CAT_CHROMA_DC_CB:
+    case CAT_CHROMA_DC_CR:
+        for (int i = 0; i < n; i++) if (coeff[i]) put(256 + (cat - CAT_CHROMA_DC_CB) * 64 + i * 16, coeff[i]);
+        break;
+    case CAT_CHROMA_AC_CB:
+    case CAT_CHROMA_AC_CR:
+        for (int i = 0; i < n; i++)
+            if (coeff[i]) put(256 + (cat - CAT_CHROMA_AC_CB) * 64 + blkIdx * 16 + kZigzag4x4[i + 1], coeff[i]);
+        break;
+    }
+}
+
+// residual_luma + residual_chroma, h264_macroblock.c:1102-1295
+int PictureDecoder::residual(int addr, std::string &err)
+{
+    MbState &mb = mbs_[addr];
+    const bool cabac = pps_.entropy_coding_mode;
+    int coeff[64];
+    auto block = [&](int cat, int blkIdx, int startIdx, int endIdx, int maxNum) -> int {
+        memset(coeff, 0, sizeof(coeff));
+        int rc = cabac ? cabac_->residual_block(addr, coeff, startIdx, endIdx, maxNum, cat, blkIdx)
+                       : residual_block_cavlc(addr, coeff, startIdx, endIdx, maxNum, cat, blkIdx);
+        if (rc != RC_SUCCESS) return rc;
+        return RC_SUCCESS;
+    };
+    if (mb.kind == MVHP_KIND_I16x16) {
+        if (block(CAT_LUMA_16x16_DC, 0, 0, 15, 16) != RC_SUCCESS) { err = "residual: Intra16x16 DC block"; return RC_FAILURE; }
+        scatter(addr, CAT_LUMA_16x16_DC, 0, coeff, 16);
+    }
+    for (int i8 = 0; i8 < 4; i8++) {
+        if (!mb.transform8x8 || !cabac) {
+            int c8[64];
+            memset(c8, 0, sizeof(c8));
+            for (int i4 = 0; i4 < 4; i4++) {
+                const int blk = i8 * 4 + i4;
+                if (mb.cbp_luma & (1 << i8)) {
+                    if (mb.kind == MVHP_KIND_I16x16) {
+                        if (block(CAT_LUMA_16x16_AC, blk, 0, 14, 15) != RC_SUCCESS) { err = "residual: Intra16x16 AC block"; return RC_FAILURE; }
+                        scatter(addr, CAT_LUMA_16x16_AC, blk, coeff, 15);
+                    } else {
+                        if (block(CAT_LUMA_4x4, blk, 0, 15, 16) != RC_SUCCESS) { err = "residual: luma 4x4 block"; return RC_FAILURE; }
+                        if (mb.transform8x8) {
+                            for (int i = 0; i < 16; i++) c8[4 * i + i4] = coeff[i]; // :1175-1184
+                        } else {
+                            scatter(addr, CAT_LUMA_4x4, blk, coeff, 16);
+                        }
+                    }
+                } else {
+                    mb.tc_luma[blk] = 0;
+                }
+            }
+            if (mb.transform8x8 && (mb.cbp_luma & (1 << i8))) scatter(addr, CAT_LUMA_8x8, i8, c8, 64);
+        } else if (mb.cbp_luma & (1 << i8)) {
+            if (block(CAT_LUMA_8x8, i8, 0, 63, 64) != RC_SUCCESS) { err = "residual: luma 8x8 block"; return RC_FAILURE; }
+            scatter(addr, CAT_LUMA_8x8, i8, coeff, 64);
+        }
+    }
+    for (int c = 0; c < 2; c++) {
+        if (mb.cbp_chroma & 3) {
+            if (block(CAT_CHROMA_DC_CB + c, 0, 0, 3, 4) != RC_SUCCESS) { err = "residual: chroma DC block"; return RC_FAILURE; }
+            scatter(addr, CAT_CHROMA_DC_CB + c, 0, coeff, 4);
+        }
+    }
+    for (int c = 0; c < 2; c++) {
+        for (int blk = 0; blk < 4; blk++) {
+            if (mb.cbp_chroma & 2) {
+                if (block(CAT_CHROMA_AC_CB + c, blk, 0, 14, 15) != RC_SUCCESS) { err = "residual: chroma AC block"; return RC_FAILURE; }
+                scatter(addr, CAT_CHROMA_AC_CB + c, blk, coeff, 15);
+            }
+        }
+    }
+    return RC_SUCCESS;
+}
+
+// ---------------------------------------------------------------------------
+// H8: CAVLC (h264_cavlc.c:79-346)
+// ---------------------------------------------------------------------------
+int PictureDecoder::nC_for(int addr, int cat, int blkIdx) const
+{
+    if (cat == CAT_CHROMA_DC_CB || cat == CAT_CHROMA_DC_CR) return -1;
+    int aA, aB, bA = 0, bB = 0, nA = 0, nB = 0;
+    if (cat == CAT_CHROMA_AC_CB || cat == CAT_CHROMA_AC_CR) {
+        const int c = cat - CAT_CHROMA_AC_CB;
+        aA = chroma_neighbour_A(addr, W_, blkIdx, &bA);
+        aB = chroma_neighbour_B(addr, W_, blkIdx, &bB);
+        if (aA >= 0) nA = mbs_[aA].tc_c[c][bA];
+        if (aB >= 0) nB = mbs_[aB].tc_c[c][bB];
+    } else {
+        aA = luma_neighbour_A(addr, W_, blkIdx, &bA);
+        aB = luma_neighbour_B(addr, W_, blkIdx, &bB);
+        if (aA >= 0) nA = mbs_[aA].tc_luma[bA];
+        if (aB >= 0) nB = mbs_[aB].tc_luma[bB];
+    }
+    if (aA >= 0 && aB >= 0) return (nA + nB + 1) >> 1;
+    if (aA >= 0) return nA;
+    if (aB >= 0) return nB;
+    return 0;
+}
+
+static int read_vlc(BitReader &br, const uint8_t *len, const uint8_t *code, int n)
+{
+    for (int i = 0; i < n; i++) {
+        if (len[i] == 0) continue;
+        if (br.peek(len[i]) == code[i]) { br.skip(len[i]); return i; }
+    }
+    return -1;
+}
+
+int PictureDecoder::residual_block_cavlc(int addr, int *coeffLevel, int startIdx, int endIdx, int maxNumCoeff, int cat,
+                                         int blkIdx)
+{
+    MbState &mb = mbs_[addr];
+    const int nC = nC_for(addr, cat, blkIdx);
+    int total = -1, t1s = 0;
+    // 9.2.1 coeff_token
+    if (nC >= 8) {
+        const unsigned v = br_.bits(6);
+        if (v == 3) { total = 0; t1s = 0; }
+        else { total = (int)(v >> 2) + 1; t1s = (int)(v & 3); if (t1s > total) return RC_FAILURE; }
+    } else if (nC == -1) {
+        for (int t = 0; t < 4 && total < 0; t++)
+            for (int n = 0; n < 5; n++) {
+                const int l = kCoeffTokenChromaDcLen[t][n];
+                if (l && br_.peek(l) == kCoeffTokenChromaDcCode[t][n]) { br_.skip(l); total = n; t1s = t; break; }
+            }
+    } else {
+        const int tab = nC < 2 ? 0 : (nC < 4 ? 1 : 2);
+        for (int t = 0; t < 4 && total < 0; t++)
+            for (int n = 0; n < 17; n++) {
+                const int l = kCoeffTokenLen[tab][t][n];
+                if (l && br_.peek(l) == kCoeffTokenCode[tab][t][n]) { br_.skip(l); total = n; t1s = t; break; }
+            }
+    }
+    if (total < 0) return RC_FAILURE;
+    // h264_cavlc.c:207-212: the count is recorded for neighbours (luma categories share tc_luma;
+    // the Intra16x16 DC count lands in slot blkIdx = 0 and is overwritten by AC block 0)
+    if (cat <= CAT_LUMA_16x16_AC) mb.tc_luma[blkIdx] = (uint8_t)total;
+    else if (cat == CAT_CHROMA_AC_CB) mb.tc_c[0][blkIdx] = (uint8_t)total;
+    else if (cat == CAT_CHROMA_AC_CR) mb.tc_c[1][blkIdx] = (uint8_t)total;
+    if (total == 0) return RC_SUCCESS;
+    if (total > maxNumCoeff) return RC_SUCCESS; // silently skipped (:218)
+
+    int level[16], run[16];
+    int suffixLength = (total > 10 && t1s < 3) ? 1 : 0;
+    for (int i = 0; i < total; i++) {
+        if (i < t1s) {
+            level[i] = 1 - 2 * (int)br_.bit();
+        } else {
+            int level_prefix = 0;
+            while (br_.bit() == 0) {
+                if (++level_prefix > 32 || br_.overrun()) return RC_FAILURE;
+            }
+            int levelCode = (level_prefix < 15 ? level_prefix : 15) << suffixLength;
+            if (suffixLength > 0 || level_prefix >= 14) {
+                int size = suffixLength;
+                if (level_prefix == 14 && suffixLength == 0) size = 4;
+                else if (level_prefix > 14) size = level_prefix - 3;
+                if (size > 0) levelCode += (int)br_.bits(size);
+            }
+            if (level_prefix >= 15 && suffixLength == 0) levelCode += 15;
+            if (level_prefix >= 16) levelCode += (1 << (level_prefix - 3)) - 4096;
+            if (i == t1s && t1s < 3) levelCode += 2;
+            level[i] = (levelCode % 2 == 0) ? ((levelCode + 2) >> 1) : ((-levelCode - 1) >> 1);
+            if (suffixLength == 0) suffixLength = 1;
+            if (abs(level[i]) > (3 << (suffixLength - 1)) && suffixLength < 6) suffixLength++;
+        }
+    }
+    int zerosLeft = 0;
+    if (total < endIdx - startIdx + 1) {
+        int tz;
+        if (cat == CAT_CHROMA_DC_CB || cat == CAT_CHROMA_DC_CR)
+            tz = read_vlc(br_, kTotalZerosChromaDcLen[total - 1], kTotalZerosChromaDcCode[total - 1], 4);
+        else
+            tz = read_vlc(br_, kTotalZerosLen[total - 1], kTotalZerosCode[total - 1], 16);
+        if (tz < 0) return RC_FAILURE;
+        zerosLeft = tz;
+    }
+    for (int i = 0; i < total - 1; i++) {
+        if (zerosLeft > 0) {
+            const int v = (zerosLeft - 1 < 6) ? zerosLeft - 1 : 6;
+            const int rb = read_vlc(br_, kRunBeforeLen[v], kRunBeforeCode[v], 15);
+            if (rb < 0) return RC_FAILURE;
+            run[i] = rb;
+        } else {
+            run[i] = 0;
+        }
+        zerosLeft -= run[i];
+        if (zerosLeft < 0) return RC_FAILURE;
+    }
+    run[total - 1] = zerosLeft;
+    int coeffNum = -1;
+    for (int i = total - 1; i >= 0; i--) {
+        coeffNum += run[i] + 1;
+        if (startIdx + coeffNum > endIdx || startIdx + coeffNum >= 64) return RC_FAILURE;
+        coeffLevel[startIdx + coeffNum] = level[i];
+    }
+    return RC_SUCCESS;
+}
+
+} // namespace h264

@@ -1,0 +1,129 @@
+// h264_frontend.h -- host side of the split decoder: Annex-B index, NAL
+// unescaping, SPS/PPS/slice-header parsing, macroblock layer, CAVLC/CABAC
+// residual decoding and Intra NxN prediction-mode derivation.  Output: one
+// packed macroblock record per macroblock (include/minivideo_hotpath.h).
+//
+// Reference functions restated here (minivideo/src/...):
+//   demuxer/esparser/esparser.c:40-143          -> index_annexb()
+//   decoder/h264/h264_nalu.c:109-249            -> Nal header, unescape_rbsp()
+//   decoder/h264/h264_parameterset.c:123-397    -> parse_sps()
+//   decoder/h264/h264_parameterset.c:812-942    -> parse_pps()
+//   decoder/h264/h264_slice.c:156-334,1013-1142 -> PictureDecoder::slice_header/slice_data
+//   decoder/h264/h264_macroblock.c:75-313,393-518,766-842,1102-1295 -> PictureDecoder::macroblock
+//   decoder/h264/h264_cavlc.c:79-346            -> PictureDecoder::residual_block_cavlc
+//   decoder/h264/h264_cabac.c:138-2563          -> h264_cabac.cpp
+//   decoder/h264/h264_intra_prediction.c:196-290,977-1083 -> derive_pred_modes
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "bitreader.h"
+#include "minivideo_hotpath.h"
+
+namespace h264 {
+
+enum { RC_UNSUPPORTED = -1, RC_FAILURE = 0, RC_SUCCESS = 1 }; // typedef.h:40-42
+
+struct Sps {
+    bool     valid = false;
+    int      profile_idc = 0, level_idc = 0, sps_id = 0;
+    int      chroma_format_idc = 1;
+    int      log2_max_frame_num = 4;
+    int      poc_type = 0, log2_max_poc_lsb = 4;
+    bool     delta_pic_order_always_zero = false;
+    int      width_mbs = 0, height_map_units = 0;
+    bool     frame_mbs_only = true;
+    bool     direct_8x8_inference = false;
+    bool     frame_cropping = false;
+    int      crop[4] = {0, 0, 0, 0};
+    bool     qpprime_y_zero_transform_bypass = false;
+};
+
+struct Pps {
+    bool valid = false;
+    int  pps_id = 0, sps_id = 0;
+    bool entropy_coding_mode = false;
+    bool bottom_field_pic_order_in_frame_present = false;
+    int  num_slice_groups_minus1 = 0;
+    bool weighted_pred = false;
+    int  weighted_bipred_idc = 0;
+    int  pic_init_qp_minus26 = 0, pic_init_qs_minus26 = 0;
+    int  chroma_qp_index_offset = 0, second_chroma_qp_index_offset = 0;
+    bool deblocking_filter_control_present = false;
+    bool constrained_intra_pred = false;
+    bool redundant_pic_cnt_present = false;
+    bool transform_8x8_mode = false;
+};
+
+// One entry of the elementary-stream sample table (bitstream_map_struct.h:46-129,
+// as filled by esparser.c:82-124): offset of the NAL header byte and the
+// distance to the next indexed NAL header (the reference's sample_size, which
+// includes the next start code), plus the true NAL payload end.
+struct EsSample {
+    size_t offset = 0;       // NAL header byte
+    size_t sample_size = 0;  // reference semantics (to next indexed NAL header byte / EOF)
+    size_t nal_size = 0;     // header + payload, start code and trailing zero bytes trimmed
+    int    nal_unit_type = 0;
+    int    nal_ref_idc = 0;
+    bool   is_idr = false;
+};
+
+int  index_annexb(const uint8_t *data, size_t size, std::vector<EsSample> &out);
+void unescape_rbsp(const uint8_t *src, size_t n, std::vector<uint8_t> &dst);
+int  parse_sps(BitReader &br, Sps &sps, std::string &err);
+int  parse_pps(BitReader &br, const Sps *sps_table /*[32]*/, Pps &pps, std::string &err);
+
+// Per-macroblock state kept for neighbour derivations (nC, ctxIdxInc, pred modes).
+struct MbState {
+    uint8_t  kind = 0;          // MVHP_KIND_*
+    uint8_t  mb_type = 0;       // raw I-slice mb_type 0..24
+    uint8_t  cbp_luma = 0, cbp_chroma = 0;
+    uint8_t  chroma_pred_mode = 0;
+    uint8_t  qp_delta_nonzero = 0;
+    uint8_t  transform8x8 = 0;
+    uint8_t  pred[16] = {0};    // final Intra4x4PredMode[16] / Intra8x8PredMode[4]
+    uint8_t  tc_luma[16] = {0}, tc_c[2][4] = {{0}}; // CAVLC TotalCoeff
+    uint32_t cbf = 0;           // CABAC coded_block_flag: bits 0-15 luma, 16 luma DC,
+                                // 17-20 Cb AC, 21-24 Cr AC, 25 Cb DC, 26 Cr DC
+};
+
+struct CabacEngine;
+
+class PictureDecoder {
+public:
+    PictureDecoder(const Sps &sps, const Pps &pps, int nal_ref_idc);
+    ~PictureDecoder();
+    // rbsp: slice NAL payload (after the NAL header byte), emulation prevention removed.
+    int decode(const uint8_t *rbsp, size_t n, uint8_t *packed, size_t packed_bytes, std::string &err);
+
+private:
+    friend struct CabacEngine;
+    int  slice_header(std::string &err);
+    int  slice_data(std::string &err);
+    int  macroblock(int addr, std::string &err);
+    void derive_pred_modes(int addr, const uint8_t prev_flag[16], const uint8_t rem[16]);
+    int  residual(int addr, std::string &err);
+    int  residual_block_cavlc(int addr, int *coeff, int startIdx, int endIdx, int maxNumCoeff, int cat, int blkIdx);
+    int  nC_for(int addr, int cat, int blkIdx) const;
+    void scatter(int addr, int cat, int blkIdx, const int *coeff, int n);
+
+    // neighbour helpers: address of MB A/B or -1
+    int mbA(int addr) const { return (addr % W_) > 0 ? addr - 1 : -1; }
+    int mbB(int addr) const { return addr >= W_ ? addr - W_ : -1; }
+
+    const Sps &sps_;
+    const Pps &pps_;
+    int        nal_ref_idc_;
+    int        W_, H_;
+    BitReader  br_;
+    std::vector<MbState> mbs_;
+    uint8_t   *out_ = nullptr;
+    int        slice_qp_ = 26, qp_prev_ = 26;
+    CabacEngine *cabac_ = nullptr;
+    bool       level_overflow_ = false;
+};
+
+} // namespace h264

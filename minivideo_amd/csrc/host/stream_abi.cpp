@@ -1,0 +1,108 @@
+// stream_abi.cpp -- mvhp_stream_* entry points of include/minivideo_hotpath.h:
+// Annex-B buffer -> sample table -> parameter sets -> packed pictures (host only).
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "h264_frontend.h"
+#include "stream_internal.h"
+
+using namespace h264;
+
+int mvhp_stream::build(std::string &err)
+{
+    if (index_annexb(data, size, samples) != RC_SUCCESS) { err = "no NAL unit found in the bitstream"; return RC_FAILURE; }
+    Sps sps_tab[32];
+    Pps pps_tab[256];
+    std::vector<uint8_t> rbsp;
+    for (size_t i = 0; i < samples.size(); i++) {
+        const EsSample &s = samples[i];
+        if (s.nal_size < 2) continue;
+        unescape_rbsp(data + s.offset + 1, s.nal_size - 1, rbsp);
+        BitReader br(rbsp.data(), rbsp.size());
+        std::string e;
+        if (s.nal_unit_type == 7) {
+            Sps sps;
+            if (parse_sps(br, sps, e) == RC_SUCCESS) sps_tab[sps.sps_id] = sps;
+            else param_errors++;
+        } else if (s.nal_unit_type == 8) {
+            Pps pps;
+            if (parse_pps(br, sps_tab, pps, e) == RC_SUCCESS) pps_tab[pps.pps_id] = pps;
+            else param_errors++;
+        } else if (s.nal_unit_type == 5) {
+            Idr idr;
+            idr.sample = i;
+            br.ue(); // first_mb_in_slice
+            br.ue(); // slice_type
+            const unsigned pid = br.ue();
+            if (pid < 256 && pps_tab[pid].valid && sps_tab[pps_tab[pid].sps_id].valid) {
+                idr.pps = pps_tab[pid];
+                idr.sps = sps_tab[idr.pps.sps_id];
+                idr.ok = true;
+            } else {
+                idr.why = "slice refers to a parameter set that was not (successfully) received";
+            }
+            idrs.push_back(idr);
+        }
+    }
+    return RC_SUCCESS;
+}
+
+int mvhp_stream::decode_packed(int k, void *packed, size_t bytes, std::string &err) const
+{
+    if (k < 0 || (size_t)k >= idrs.size()) { err = "IDR index out of range"; return RC_FAILURE; }
+    const Idr &idr = idrs[k];
+    if (!idr.ok) { err = idr.why; return RC_FAILURE; }
+    const EsSample &s = samples[idr.sample];
+    std::vector<uint8_t> rbsp;
+    unescape_rbsp(data + s.offset + 1, s.nal_size - 1, rbsp);
+    PictureDecoder pd(idr.sps, idr.pps, s.nal_ref_idc);
+    return pd.decode(rbsp.data(), rbsp.size(), (uint8_t *)packed, bytes, err);
+}
+
+static thread_local std::string g_stream_err;
+
+extern "C" {
+
+MVHP_EXPORT const char *mvhp_stream_last_error(void) { return g_stream_err.c_str(); }
+
+MVHP_EXPORT int mvhp_stream_open(const uint8_t *data, size_t size, mvhp_stream_t **out)
+{
+    if (!out || !data) return MVHP_FAILURE;
+    *out = nullptr;
+    mvhp_stream *s = new mvhp_stream();
+    s->data = data;
+    s->size = size;
+    if (s->build(g_stream_err) != RC_SUCCESS) { delete s; return MVHP_FAILURE; }
+    *out = s;
+    return MVHP_SUCCESS;
+}
+
+MVHP_EXPORT void mvhp_stream_close(mvhp_stream_t *s) { delete s; }
+
+MVHP_EXPORT int mvhp_stream_idr_count(const mvhp_stream_t *s) { return s ? (int)s->idrs.size() : 0; }
+
+MVHP_EXPORT int mvhp_stream_params(const mvhp_stream_t *s, int idr, mvhp_stream_params_t *out)
+{
+    if (!s || !out || idr < 0 || (size_t)idr >= s->idrs.size() || !s->idrs[idr].ok) return MVHP_FAILURE;
+    const mvhp_stream::Idr &i = s->idrs[idr];
+    out->width_mbs = (uint32_t)i.sps.width_mbs;
+    out->height_mbs = (uint32_t)i.sps.height_map_units;
+    out->chroma_qp_index_offset = i.pps.chroma_qp_index_offset;
+    out->second_chroma_qp_index_offset = i.pps.second_chroma_qp_index_offset;
+    out->flags = 0;
+    return MVHP_SUCCESS;
+}
+
+MVHP_EXPORT int mvhp_stream_decode_packed(const mvhp_stream_t *s, int idr, void *packed, size_t packed_bytes)
+{
+    if (!s || !packed) return MVHP_FAILURE;
+    std::string err;
+    const int rc = s->decode_packed(idr, packed, packed_bytes, err);
+    if (rc != RC_SUCCESS) g_stream_err = err;
+    return rc;
+}
+
+} // extern "C"

@@ -1,0 +1,24 @@
+// stream_internal.h -- the parsed elementary stream behind mvhp_stream_t.
+#pragma once
+#include <string>
+#include <vector>
+
+#include "h264_frontend.h"
+
+struct mvhp_stream {
+    struct Idr {
+        size_t      sample = 0;   // index into samples
+        h264::Sps   sps;          // parameter sets in force when this picture was reached
+        h264::Pps   pps;
+        bool        ok = false;
+        std::string why;
+    };
+    const uint8_t *data = nullptr;
+    size_t size = 0;
+    std::vector<h264::EsSample> samples;
+    std::vector<Idr> idrs;
+    int param_errors = 0;
+
+    int build(std::string &err);
+    int decode_packed(int idr, void *packed, size_t bytes, std::string &err) const;
+};
