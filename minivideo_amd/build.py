@@ -71,8 +71,21 @@ def build_oracle(force=False):
     return ORACLE
 
 
+CLI = os.path.join(PKG, "mini_thumbnailer")
+
+
+def build_cli(force=False):
+    src = [os.path.join(ROOT, "tools", "mini_thumbnailer.cpp")]
+    if not force and not _newer(CLI, src + [LIB, os.path.join(ROOT, "include", "minivideo.h")]):
+        return CLI
+    _run(["g++", "-O2", "-std=c++17", "-I" + os.path.join(ROOT, "include"), src[0], "-L" + PKG, "-lminivideo",
+          "-Wl,-rpath,$ORIGIN", "-o", CLI])
+    return CLI
+
+
 def build_all(force=False):
     build_product(force)
+    build_cli(force)
     build_generator(force)
     build_oracle(force)
 

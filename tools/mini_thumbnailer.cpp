@@ -1,0 +1,64 @@
+// tools/mini_thumbnailer.cpp -- a small thumbnailer CLI over libminivideo's public API with the
+// same options as the reference's mini_thumbnailer (mini_thumbnailer/src/main.cpp:47-302):
+//   -i <file> [-o <dir>] [-f jpg|png|bmp|tga|yuv420|yuv444] [-q 1..99] [-n 1..999] [-e unfiltered|ordered|distributed]
+// The stock mini_thumbnailer also builds unchanged against include/minivideo.h; this file exists so
+// that the GPU box (which has no copy of the reference) has a CLI to run.
+#include <minivideo.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+int main(int argc, char *argv[])
+{
+    const char *in = nullptr, *outdir = nullptr;
+    int fmt = PICTURE_JPG, quality = 75, number = 1, mode = PICTURE_UNFILTERED;
+    bool help = false;
+    for (int i = 1; i < argc; i++) {
+        const bool has = i + 1 < argc;
+        if (!strcmp(argv[i], "-i") && has) in = argv[++i];
+        else if (!strcmp(argv[i], "-o") && has) outdir = argv[++i];
+        else if (!strcmp(argv[i], "-f") && has) {
+            const char *f = argv[++i];
+            if (!strcmp(f, "jpg")) fmt = PICTURE_JPG;
+            else if (!strcmp(f, "png")) fmt = PICTURE_PNG;
+            else if (!strcmp(f, "bmp")) fmt = PICTURE_BMP;
+            else if (!strcmp(f, "tga")) fmt = PICTURE_TGA;
+            else if (!strcmp(f, "yuv420")) fmt = PICTURE_YUV420;
+            else if (!strcmp(f, "yuv444")) fmt = PICTURE_YUV444;
+            else fprintf(stderr, "-f : No valid picture format specified\n");
+        } else if (!strcmp(argv[i], "-q") && has) {
+            const int q = atoi(argv[++i]);
+            if (q > 0 && q < 100) quality = q;
+        } else if (!strcmp(argv[i], "-n") && has) {
+            const int n = atoi(argv[++i]);
+            if (n > 0 && n < 1000) number = n;
+        } else if (!strcmp(argv[i], "-e") && has) {
+            const char *e = argv[++i];
+            if (!strcmp(e, "unfiltered")) mode = PICTURE_UNFILTERED;
+            else if (!strcmp(e, "ordered")) mode = PICTURE_ORDERED;
+            else if (!strcmp(e, "distributed")) mode = PICTURE_DISTRIBUTED;
+            else fprintf(stderr, "-e : No valid extraction mode specified\n");
+        } else if (!strcmp(argv[i], "-h") || !strcmp(argv[i], "--help")) help = true;
+        else fprintf(stderr, "* Unknown argument '%s'\n", argv[i]);
+    }
+    if (!in || help) {
+        printf("* Usage:\nmini_thumbnailer -i <filepath> [-o <directory>] [-f picture_format][-q picture_quality]"
+               "[-n picture_number] [-e extraction_mode]\n");
+        return EXIT_FAILURE;
+    }
+    minivideo_print_infos();
+    minivideo_endianness();
+    MediaFile_t *media = nullptr;
+    int rc = minivideo_open(in, &media);
+    int decode_rc = FAILURE;
+    if (rc == SUCCESS) {
+        rc = minivideo_parse(media, false, true, false);
+        if (rc == SUCCESS) decode_rc = minivideo_decode(media, outdir, fmt, quality, number, mode);
+        rc = minivideo_close(&media);
+    }
+    // like the reference, the exit status reflects minivideo_close (main.cpp:285-298); the decode status
+    // is reported on stderr so that scripts can still see it
+    if (decode_rc != SUCCESS) fprintf(stderr, "mini_thumbnailer: decode did not succeed (rc=%d)\n", decode_rc);
+    return rc == SUCCESS ? EXIT_SUCCESS : EXIT_FAILURE;
+}
