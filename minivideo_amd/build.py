@@ -41,13 +41,26 @@ def build_product(force=False):
             + glob.glob(os.path.join(CSRC, "*", "*.inc")) + glob.glob(os.path.join(ROOT, "include", "*.h")))
     if not force and not _newer(LIB, hip_src + host_src + hdrs):
         return LIB
-    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden",
-           "-pthread", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(CSRC, "hip"),
-           "-I" + os.path.join(CSRC, "host"), "-o", LIB]
-    cmd += hip_src
-    for s in host_src:
-        cmd += ["-x", "c++", s]
-    _run(cmd)
+    inc = ["-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(CSRC, "hip"), "-I" + os.path.join(CSRC, "host")]
+    objdir = os.path.join(PKG, "build")
+    os.makedirs(objdir, exist_ok=True)
+    objs = []
+    for s in host_src:  # host C++ is compiled on its own: mixing `-x c++` inputs into the hipcc line loses --offload-arch
+        o = os.path.join(objdir, os.path.basename(s)[:-4] + ".o")
+        if force or _newer(o, [s] + hdrs):
+            _run(["g++", "-O2", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-pthread", "-c", s, "-o", o] + inc)
+        objs.append(o)
+    for s in hip_src:   # device + host objects of the kernels, gfx950 only
+        o = os.path.join(objdir, os.path.basename(s)[:-4] + ".hip.o")
+        if force or _newer(o, [s] + hdrs):
+            _run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wno-unused-value",
+                  "-c", s, "-o", o] + inc)
+        objs.append(o)
+    _run([HIPCC, "--offload-arch=gfx950", "--hip-link", "-shared", "-fPIC", "-pthread", "-o", LIB] + objs)
+    blob = open(LIB, "rb").read()
+    if b"amdgcn-amd-amdhsa--gfx950" not in blob:
+        os.remove(LIB)
+        raise RuntimeError("libminivideo.so was built without a gfx950 code object")
     return LIB
 
 
