@@ -31,6 +31,7 @@ namespace mvhp {
 // LDS layout
 // ---------------------------------------------------------------------------
 struct __attribute__((aligned(16))) WaveLds {
+    uint8_t stage[MVHP_MB_BYTES]; // the packed record of the macroblock being reconstructed (prefetched one ahead)
     int16_t res[384];      // residuals, MB raster: luma y*16+x | 256+Cb y*8+x | 320+Cr
     uint8_t T[17 * 32 + 16]; // luma tile: row 0 = top neighbours; byte 15 = left/corner, 16..31 samples;
                            // row 0 bytes 32..39 = up-right neighbours
@@ -48,8 +49,8 @@ struct __attribute__((aligned(16))) BlockLds {
     int     ls4[18];       // LevelScale4x4 classes, 16*normAdjust (h264.c:427-435)
     int     ls8[36];       // LevelScale8x8 classes (h264.c:438-446)
     uint8_t cls8[64];      // 8x8 position -> class
-    uint8_t tab4[9 * 16];  // Intra4x4 mode tables: k | type<<5
-    uint8_t tab8[9 * 64];  // Intra8x8 mode tables
+    uint32_t tap4[2 * 9 * 16]; // Intra4x4: [up-right unavailable][mode][sample] -> three byte offsets into the tile
+    uint32_t tap8[9 * 64];     // Intra8x8: [mode][sample] -> three indices into the filtered edge array E8
 };
 
 __device__ static const int c_v4x4[18] = {10, 16, 13, 11, 18, 14, 13, 20, 16, 14, 23, 18, 16, 25, 20, 18, 29, 23};
@@ -106,6 +107,32 @@ __device__ int mode_entry(int n, int mode, int x, int y)
     default: break;
     }
     return k | (t << 5);
+}
+
+// Every directional mode reduces to ONE formula, (a + 2b + c + 2) >> 2, by choosing the taps:
+// copy EE[k] = taps (k,k,k); (EE[k]+EE[k+1]+1)>>1 = taps (k,k+1,k) because (2a+2b+2)>>2 == (a+b+1)>>1.
+// tap4 entry: three bytes, each the offset (+33) of the tap relative to the tile index of the
+// block's top-left sample: top[i] -> -32+i, corner -> -33, left[j] -> 32j-1 (tile rows are 32 bytes).
+__device__ uint32_t tap4_entry(int mode, int x, int y, bool no_upright)
+{
+    const int e = mode_entry(4, mode, x, y), k = e & 31, t = e >> 5;
+    const int idx[3] = {k, (t == 0) ? k : k + 1, (t == 2) ? k + 2 : k};
+    uint32_t out = 0;
+    for (int q = 0; q < 3; q++) {
+        const int i = idx[q];
+        int off;
+        if (i >= 6) off = -32 + min(i - 7, no_upright ? 3 : 7);
+        else off = 32 * min(5 - i, 3) - 1;
+        out |= (uint32_t)(off + 33) << (8 * q);
+    }
+    return out;
+}
+// tap8 entry: three indices into E8 (EE8 index space of mode_entry(8,...)), clamped to the replicated ends.
+__device__ uint32_t tap8_entry(int mode, int x, int y)
+{
+    const int e = mode_entry(8, mode, x, y), k = e & 31, t = e >> 5;
+    const int i0 = k, i1 = min((t == 0) ? k : k + 1, 27), i2 = min((t == 2) ? k + 2 : k, 27);
+    return (uint32_t)i0 | ((uint32_t)i1 << 8) | ((uint32_t)i2 << 16);
 }
 
 // ---------------------------------------------------------------------------
@@ -309,57 +336,68 @@ __device__ __forceinline__ void residual_stage(WaveLds &W, const BlockLds &B, co
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ int sum4(uint32_t w) { return (int)__builtin_amdgcn_sad_u8(w, 0u, 0u); }
 
-// Intra 4x4 block: lanes 0..15 (x = lane&3, y = lane>>2).
-// h264_intra_prediction.c:315-483 + transform4x4_luma (h264_transform.c:121-156).
-__device__ __forceinline__ void predict_4x4(WaveLds &W, const BlockLds &B, int lane, int blk, int mode,
-                                            bool A, bool Bv, bool C, bool D, bool has_res)
+// Availability of the neighbours of the 16 luma 4x4 blocks, one bit per luma4x4BlkIdx
+// (deriv_neighbouringlocations by geometry, h264_spatial.c:739-786; the blkIdx 3/11 rule of
+// h264_intra_prediction.c:410-412).
+struct Avail4 { uint32_t left, up, upleft, upright; };
+__device__ __forceinline__ Avail4 avail4(bool A, bool Bv, bool C, bool D)
 {
-    const int xO = (((blk >> 2) & 1) << 3) | ((blk & 1) << 2);
-    const int yO = ((blk >> 3) << 3) | (((blk >> 1) & 1) << 2);
-    const bool left = (xO > 0) || A;
-    const bool up = (yO > 0) || Bv;
-    const bool upleft = (xO > 0) ? ((yO > 0) || Bv) : ((yO > 0) ? A : D);
-    bool upright;
-    if (xO + 4 > 15) upright = (yO == 0) ? C : false;
-    else if (blk == 3 || blk == 11) upright = false;
-    else upright = (yO == 0) ? Bv : true;
+    constexpr uint32_t X0 = (1u << 0) | (1u << 2) | (1u << 8) | (1u << 10);   // blocks with xO == 0
+    constexpr uint32_t Y0 = (1u << 0) | (1u << 1) | (1u << 4) | (1u << 5);    // blocks with yO == 0
+    Avail4 a;
+    a.left = A ? 0xffffu : (0xffffu & ~X0);
+    a.up = Bv ? 0xffffu : (0xffffu & ~Y0);
+    a.upleft = (0xffffu & ~(X0 | Y0)) | (Bv ? ((1u << 1) | (1u << 4) | (1u << 5)) : 0u) |
+               (A ? ((1u << 2) | (1u << 8) | (1u << 10)) : 0u) | (D ? 1u : 0u);
+    a.upright = ((1u << 2) | (1u << 6) | (1u << 8) | (1u << 9) | (1u << 10) | (1u << 12) | (1u << 14)) |
+                (Bv ? ((1u << 0) | (1u << 1) | (1u << 4)) : 0u) | (C ? (1u << 5) : 0u);
+    return a;
+}
+
+// Intra 4x4 macroblock: 16 dependent block steps, lanes 0..15 own one sample each.
+// h264_intra_prediction.c:161-177, :315-483, :496-960 + transform4x4_luma (h264_transform.c:121-156).
+__device__ __forceinline__ void predict_mb_4x4(WaveLds &W, const BlockLds &B, int lane, uint32_t m0, uint32_t m1,
+                                               uint32_t m2, uint32_t m3, bool A, bool Bv, bool C, bool D, bool has_res)
+{
+    const Avail4 av = avail4(A, Bv, C, D);
+    // neighbours each mode needs, 3 bits per mode: bit0 left, bit1 up, bit2 up-left (mode 2 = DC handled apart)
+    constexpr uint32_t REQ = (2u << 0) | (1u << 3) | (0u << 6) | (2u << 9) | (7u << 12) | (7u << 15) | (7u << 18) |
+                             (2u << 21) | (1u << 24);
+    const int rmask = has_res ? -1 : 0;
     if (lane < 16) {
-        const int x = lane & 3, y = lane >> 2;
-        const uint8_t *Trow = &W.T[yO * 32 + 16 + xO];        // p[0,-1] of this block
-        const uint8_t *Tcol = &W.T[(yO + 1) * 32 + 15 + xO];  // p[-1,0]
-        int pred = 0;
-        if (mode == 2) {
-            const int sumH = sum4(*reinterpret_cast<const uint32_t *>(Trow));
-            const int sumV = Tcol[0] + Tcol[32] + Tcol[64] + Tcol[96];
-            if (left && up) pred = (sumH + sumV + 4) >> 3;
-            else if (left) pred = (sumV + 2) >> 2;
-            else if (up) pred = (sumH + 2) >> 2;
-            else pred = 128;
-        } else {
-            bool ok;
-            switch (mode) {
-            case 0: case 3: case 7: ok = up; break;
-            case 1: case 8: ok = left; break;
-            default: ok = left && up && upleft; break; // 4, 5, 6
-            }
-            if (ok) {
-                const int e = B.tab4[mode * 16 + lane];
-                const int k = e & 31, t = e >> 5;
-                const int maxi = upright ? 7 : 3;
-                int v[3];
+        const int pix = (lane >> 2) * 32 + (lane & 3);   // this lane's sample inside a block, tile units
+        const int rpix = (lane >> 2) * 16 + (lane & 3);  // same in the residual array
+        const uint8_t *T = W.T;
 #pragma unroll
-                for (int q = 0; q < 3; q++) {
-                    const int idx = k + q;
-                    int a;
-                    if (idx >= 6) a = (int)Trow[min(idx - 7, maxi)];
-                    else a = (int)Tcol[min(5 - idx, 3) * 32];
-                    v[q] = a;
-                }
-                pred = (t == 0) ? v[0] : (t == 1) ? ((v[0] + v[1] + 1) >> 1) : ((v[0] + 2 * v[1] + v[2] + 2) >> 2);
+        for (int blk = 0; blk < 16; blk++) {
+            const int xO = (((blk >> 2) & 1) << 3) | ((blk & 1) << 2);
+            const int yO = ((blk >> 3) << 3) | (((blk >> 1) & 1) << 2);
+            const int base = (yO + 1) * 32 + 16 + xO;     // tile index of the block's top-left sample
+            const uint32_t mw = (blk < 4) ? m0 : (blk < 8) ? m1 : (blk < 12) ? m2 : m3;
+            const uint32_t mode = (mw >> ((blk & 3) * 8)) & 255u;
+            const uint32_t avail = ((av.left >> blk) & 1u) | (((av.up >> blk) & 1u) << 1) | (((av.upleft >> blk) & 1u) << 2);
+            const int r = (int)W.res[yO * 16 + xO + rpix] & rmask;
+            int pred;
+            if (mode == 2) {
+                const int sumH = sum4(*reinterpret_cast<const uint32_t *>(&T[base - 32]));
+                const int sumV = T[base - 1] + T[base + 31] + T[base + 63] + T[base + 95];
+                // (avail & 3): 3 both, 1 left only, 2 up only, 0 none
+                const int both = (sumH + sumV + 4) >> 3, l = (sumV + 2) >> 2, u = (sumH + 2) >> 2;
+                pred = ((avail & 3u) == 3u) ? both : ((avail & 3u) == 1u) ? l : ((avail & 3u) == 2u) ? u : 128;
+            } else {
+                // a mode whose neighbours are missing leaves the prediction at 0 (:442); so does an invalid mode
+                const uint32_t req = (REQ >> (min(mode, 8u) * 3)) & 7u;
+                const int okmask = (((req & ~avail) == 0u) && (mode < 9u)) ? -1 : 0;
+                const uint32_t row = (((av.upright >> blk) & 1u) ? 0u : 9u) + min(mode, 8u);
+                const uint32_t e = B.tap4[row * 16 + lane];
+                const int a = T[base - 33 + (int)(e & 255)];
+                const int b = T[base - 33 + (int)((e >> 8) & 255)];
+                const int c = T[base - 33 + (int)(e >> 16)];
+                pred = ((a + 2 * b + c + 2) >> 2) & okmask;
             }
+            W.T[base + pix] = (uint8_t)clip255(pred + r);
+            WAVE_SYNC();
         }
-        const int r = has_res ? (int)W.res[(yO + y) * 16 + xO + x] : 0;
-        W.T[(yO + y + 1) * 32 + 16 + xO + x] = (uint8_t)clip255(pred + r);
     }
     WAVE_SYNC();
 }
@@ -415,11 +453,10 @@ __device__ __forceinline__ void predict_8x8(WaveLds &W, const BlockLds &B, int l
             case 1: case 8: ok = left; break;
             default: ok = left && up && upleft; break;
             }
-            if (ok) {
-                const int e = B.tab8[mode * 64 + lane];
-                const int k = e & 31, t = e >> 5;
-                const int v0 = W.E8[k], v1 = W.E8[min(k + 1, 27)], v2 = W.E8[min(k + 2, 27)];
-                pred = (t == 0) ? v0 : (t == 1) ? ((v0 + v1 + 1) >> 1) : ((v0 + 2 * v1 + v2 + 2) >> 2);
+            if (ok && mode < 9) {
+                const uint32_t e = B.tap8[mode * 64 + lane];
+                const int v0 = W.E8[e & 255], v1 = W.E8[(e >> 8) & 255], v2 = W.E8[e >> 16];
+                pred = (v0 + 2 * v1 + v2 + 2) >> 2;
             }
         }
         const int r = has_res ? (int)W.res[(yO + y) * 16 + xO + x] : 0;
@@ -577,8 +614,9 @@ __global__ __launch_bounds__(NW * 64) void recon_rows_kernel(ReconArgs a)
         else k = 5;
         B.cls8[i] = (uint8_t)k;
     }
-    for (int i = threadIdx.x; i < 9 * 16; i += NW * 64) B.tab4[i] = (uint8_t)mode_entry(4, i >> 4, i & 3, (i >> 2) & 3);
-    for (int i = threadIdx.x; i < 9 * 64; i += NW * 64) B.tab8[i] = (uint8_t)mode_entry(8, i >> 6, i & 7, (i >> 3) & 7);
+    for (int i = threadIdx.x; i < 2 * 9 * 16; i += NW * 64)
+        B.tap4[i] = tap4_entry((i >> 4) % 9, i & 3, (i >> 2) & 3, i >= 9 * 16);
+    for (int i = threadIdx.x; i < 9 * 64; i += NW * 64) B.tap8[i] = tap8_entry(i >> 6, i & 7, (i >> 3) & 7);
     if (threadIdx.x < 16) B.progress[threadIdx.x] = 0;
     if (threadIdx.x == 16) B.abort_flag = 0;
     __syncthreads();
@@ -592,17 +630,31 @@ __global__ __launch_bounds__(NW * 64) void recon_rows_kernel(ReconArgs a)
     volatile int *progress = B.progress;
     volatile int *abort_flag = &B.abort_flag;
 
+    // The packed record is prefetched one macroblock ahead (global -> registers of lanes 0..49,
+    // 16 B each = the 800 contiguous bytes), then staged through LDS for the lanes that consume it.
+    int4 pre = make_int4(0, 0, 0, 0);
+    if (wave < H && lane < 50) pre = *reinterpret_cast<const int4 *>(fpacked + (size_t)(wave * W) * MVHP_MB_BYTES + lane * 16);
+
     int done = 0; // macroblocks completed by this wave
     for (int row = wave; row < H; row += NW) {
         const int pass = row / NW;
         const int up_base = ((wave == 0) ? (pass - 1) : pass) * W; // MBs the upper wave finished before its row (row-1)
         const bool Bv = row > 0;
         for (int mbx = 0; mbx < W; mbx++) {
-            const uint8_t *mbp = fpacked + (size_t)(row * W + mbx) * MVHP_MB_BYTES;
-            // header: wave-uniform -> scalar loads
-            const uint32_t h0 = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const uint32_t *>(mbp));
-            const uint32_t h1 = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const uint32_t *>(mbp + 4));
-            const uint32_t nz = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const uint32_t *>(mbp + 8));
+            if (lane < 50) *reinterpret_cast<int4 *>(&Wv.stage[lane * 16]) = pre;
+            {   // next record of this wave: same row, or the first one of its next row
+                int nrow = row, nx = mbx + 1;
+                if (nx == W) { nrow = row + NW; nx = 0; }
+                if (nrow < H && lane < 50)
+                    pre = *reinterpret_cast<const int4 *>(fpacked + (size_t)(nrow * W + nx) * MVHP_MB_BYTES + lane * 16);
+            }
+            WAVE_SYNC();
+            const uint8_t *mbp = Wv.stage;
+            const int4 ha = *reinterpret_cast<const int4 *>(mbp), hb = *reinterpret_cast<const int4 *>(mbp + 16);
+            // header: wave-uniform -> scalars
+            const uint32_t h0 = __builtin_amdgcn_readfirstlane((uint32_t)ha.x);
+            const uint32_t h1 = __builtin_amdgcn_readfirstlane((uint32_t)ha.y);
+            const uint32_t nz = __builtin_amdgcn_readfirstlane((uint32_t)ha.z);
             const int kind = h0 & 255, qpy = (h0 >> 8) & 255;
             const int cmode = (h0 >> 24) & 255, i16mode = h1 & 255;
             const bool A = mbx > 0, C = Bv && (mbx < W - 1), D = A && Bv;
@@ -651,17 +703,13 @@ __global__ __launch_bounds__(NW * 64) void recon_rows_kernel(ReconArgs a)
             if (kind == MVHP_KIND_I16x16) {
                 predict_16x16(Wv, lane, i16mode, A, Bv, res_luma);
             } else if (kind == MVHP_KIND_I4x4) {
-                const uint32_t m0 = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const uint32_t *>(mbp + 12));
-                const uint32_t m1 = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const uint32_t *>(mbp + 16));
-                const uint32_t m2 = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const uint32_t *>(mbp + 20));
-                const uint32_t m3 = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const uint32_t *>(mbp + 24));
-                for (int blk = 0; blk < 16; blk++) {
-                    const uint32_t mw = (blk < 4) ? m0 : (blk < 8) ? m1 : (blk < 12) ? m2 : m3;
-                    const int mode = (mw >> ((blk & 3) * 8)) & 255;
-                    predict_4x4(Wv, B, lane, blk, mode, A, Bv, C, D, res_luma);
-                }
+                const uint32_t m0 = __builtin_amdgcn_readfirstlane((uint32_t)ha.w);
+                const uint32_t m1 = __builtin_amdgcn_readfirstlane((uint32_t)hb.x);
+                const uint32_t m2 = __builtin_amdgcn_readfirstlane((uint32_t)hb.y);
+                const uint32_t m3 = __builtin_amdgcn_readfirstlane((uint32_t)hb.z);
+                predict_mb_4x4(Wv, B, lane, m0, m1, m2, m3, A, Bv, C, D, res_luma);
             } else {
-                const uint32_t m0 = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const uint32_t *>(mbp + 12));
+                const uint32_t m0 = __builtin_amdgcn_readfirstlane((uint32_t)ha.w);
                 for (int blk = 0; blk < 4; blk++)
                     predict_8x8(Wv, B, lane, blk, (m0 >> (blk * 8)) & 255, A, Bv, C, D, res_luma);
             }
