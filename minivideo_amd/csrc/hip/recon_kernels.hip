@@ -159,10 +159,10 @@ __device__ __forceinline__ void idct4x4(int d[16])
         int g1 = d[0 + j] - d[8 + j];
         int g2 = (d[4 + j] >> 1) - d[12 + j];
         int g3 = d[4 + j] + (d[12 + j] >> 1);
-        d[0 + j]  = (g0 + g3 + 32) >> 6;
-        d[4 + j]  = (g1 + g2 + 32) >> 6;
-        d[8 + j]  = (g1 - g2 + 32) >> 6;
-        d[12 + j] = (g0 - g3 + 32) >> 6;
+        d[0 + j]  = (g0 + g3) >> 6;   // the +32 rounding term was added to d[0] by the caller: every output
+        d[4 + j]  = (g1 + g2) >> 6;   // contains d[0] exactly once, unshifted, so this equals (h + 32) >> 6
+        d[8 + j]  = (g1 - g2) >> 6;
+        d[12 + j] = (g0 - g3) >> 6;
     }
 }
 
@@ -201,7 +201,14 @@ __device__ __forceinline__ bool hneg(int i, int k)
     return (i == 1 && k >= 2) || (i == 2 && (k == 1 || k == 2)) || (i == 3 && (k & 1));
 }
 
-__device__ __forceinline__ int sat9(int r) { return min(max(r, -256), 255); }
+// Two residuals -> packed int16 with signed saturation (v_cvt_pk_i16_i32).  Saturating is exact for the
+// final sample: clip255(pred + r) only depends on r inside [-255, 255].
+__device__ __forceinline__ int pack_res(int a, int b)
+{
+    typedef short short2_t __attribute__((ext_vector_type(2)));
+    const short2_t v = __builtin_amdgcn_cvt_pk_i16(a, b);
+    return __builtin_bit_cast(int, v);
+}
 
 // Residual stage for one macroblock: fills W.res. Lanes: 4x4 path lane b < 24
 // owns block b (0-15 luma, 16-19 Cb, 20-23 Cr); 8x8 path lanes 0-31 own one
@@ -232,6 +239,7 @@ __device__ __forceinline__ void residual_stage(WaveLds &W, const BlockLds &B, co
                 for (int j = 0; j < 8; j++)
                     d[j] = (d[j] * B.ls8[m * 6 + B.cls8[row * 8 + j]] + rnd) >> sh;
             }
+            if (row == 0) d[0] += 32; // rounding term of the final (m + 32) >> 6, see idct4x4
             idct8_1d(d);
 #pragma unroll
             for (int j = 0; j < 8; j++) W.scr[blk * 64 + row * 8 + j] = d[j];
@@ -245,7 +253,7 @@ __device__ __forceinline__ void residual_stage(WaveLds &W, const BlockLds &B, co
             idct8_1d(d);
             const int xO = (blk & 1) * 8, yO = (blk >> 1) * 8;
 #pragma unroll
-            for (int i = 0; i < 8; i++) W.res[(yO + i) * 16 + xO + col] = (int16_t)sat9((d[i] + 32) >> 6);
+            for (int i = 0; i < 8; i++) W.res[(yO + i) * 16 + xO + col] = (int16_t)(pack_res(d[i] >> 6, 0) & 0xffff);
         }
         WAVE_SYNC();
     }
@@ -253,6 +261,7 @@ __device__ __forceinline__ void residual_stage(WaveLds &W, const BlockLds &B, co
     // ---- 4x4 blocks (transform_4x4_residual, h264_transform.c:1049-1191) ----
     const int first = (kind == MVHP_KIND_I8x8) ? 16 : 0;
     const bool act = (lane >= first) && (lane < 24);
+    const bool all_ge24 = (qpy > 23) && (qpc_cb > 23) && (qpc_cr > 23); // wave-uniform
     int d[16];
     if (act) {
         const int4 r0 = *reinterpret_cast<const int4 *>(coef + lane * 16);
@@ -292,24 +301,27 @@ __device__ __forceinline__ void residual_stage(WaveLds &W, const BlockLds &B, co
             if (qpy > 36) dc = (int)((unsigned)(f * lsA) << ((s - 6) & 31));
             else dc = (int)((unsigned)(f * lsA) + (1u << ((5 - s) & 31))) >> ((6 - s) & 31);
         }
-        // quant4x4, h264_transform.c:1100-1134
-        if (qP > 23) {
+        // quant4x4, h264_transform.c:1100-1134.  qP differs between luma and chroma lanes, so the two
+        // cases are merged: ((c*LS + rnd) >> shr) << shl with (shr, rnd) = (0, 0) when qP > 23.
+        if (all_ge24) {
+            const int shl = s - 4;
 #pragma unroll
             for (int i = 0; i < 16; i++) {
                 const int r = i >> 2, c = i & 3;
                 const int ls = ((r & 1) == 0 && (c & 1) == 0) ? lsA : (((r & 1) && (c & 1)) ? lsB : lsC);
-                d[i] = (int)((unsigned)(d[i] * ls) << ((s - 4) & 31));
+                d[i] = (int)((unsigned)(d[i] * ls) << shl);
             }
         } else {
-            const int rnd = 1 << ((3 - s) & 31), sh = (4 - s) & 31;
+            const int shl = max(s - 4, 0), shr = max(4 - s, 0), rnd = (1 << shr) >> 1;
 #pragma unroll
             for (int i = 0; i < 16; i++) {
                 const int r = i >> 2, c = i & 3;
                 const int ls = ((r & 1) == 0 && (c & 1) == 0) ? lsA : (((r & 1) && (c & 1)) ? lsB : lsC);
-                d[i] = (d[i] * ls + rnd) >> sh;
+                d[i] = (int)((unsigned)((d[i] * ls + rnd) >> shr) << shl);
             }
         }
         if (keep_dc) d[0] = dc;
+        d[0] += 32;
         idct4x4(d);
         int base, stride;
         if (!chroma) {
@@ -323,8 +335,8 @@ __device__ __forceinline__ void residual_stage(WaveLds &W, const BlockLds &B, co
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             int2 pk;
-            pk.x = (sat9(d[i * 4 + 0]) & 0xffff) | (sat9(d[i * 4 + 1]) << 16);
-            pk.y = (sat9(d[i * 4 + 2]) & 0xffff) | (sat9(d[i * 4 + 3]) << 16);
+            pk.x = pack_res(d[i * 4 + 0], d[i * 4 + 1]);
+            pk.y = pack_res(d[i * 4 + 2], d[i * 4 + 3]);
             *reinterpret_cast<int2 *>(&W.res[base + i * stride]) = pk;
         }
     }
@@ -630,6 +642,33 @@ __global__ __launch_bounds__(NW * 64) void recon_rows_kernel(ReconArgs a)
     volatile int *progress = B.progress;
     volatile int *abort_flag = &B.abort_flag;
 
+    // Per-lane copy plans (fixed for the whole kernel) so that the per-macroblock neighbour traffic is a
+    // couple of predicated LDS moves instead of a ladder of lane-range branches.
+    //  top fetch : lanes 0-3 luma top, 4-5 luma up-right, 6-7 Cb top, 8-9 Cr top (one dword each)
+    //  keep      : lanes 0-2 corners, 16-31 luma right column, 32-47 chroma right columns (one byte each)
+    //  bottom    : lanes 48-51 luma, 52-53 Cb, 54-55 Cr bottom rows -> line buffer (one dword each)
+    uint8_t *top_dst = Wv.T, *keep_src = Wv.T, *keep_dst = Wv.T, *keep_dst2 = Wv.T, *bot_src = Wv.T, *bot_dst = line_y;
+    const uint8_t *top_src = line_y;
+    int top_mul = 0, bot_mul = 0;
+    if (lane < 4) { top_dst = &Wv.T[16 + lane * 4]; top_src = &line_y[lane * 4]; top_mul = 16; }
+    else if (lane < 6) { top_dst = &Wv.T[32 + (lane - 4) * 4]; top_src = &line_y[16 + (lane - 4) * 4]; top_mul = 16; }
+    else if (lane < 8) { top_dst = &Wv.TC[0][8 + (lane - 6) * 4]; top_src = &line_cb[(lane - 6) * 4]; top_mul = 8; }
+    else if (lane < 10) { top_dst = &Wv.TC[1][8 + (lane - 8) * 4]; top_src = &line_cr[(lane - 8) * 4]; top_mul = 8; }
+    const bool keep_act = (lane < 3) || (lane >= 16 && lane < 48);
+    if (lane == 0) { keep_src = &Wv.T[31]; keep_dst = keep_dst2 = &Wv.T[15]; }
+    else if (lane == 1) { keep_src = &Wv.TC[0][15]; keep_dst = keep_dst2 = &Wv.TC[0][7]; }
+    else if (lane == 2) { keep_src = &Wv.TC[1][15]; keep_dst = keep_dst2 = &Wv.TC[1][7]; }
+    else if (lane >= 16 && lane < 32) {
+        keep_src = &Wv.T[(lane - 15) * 32 + 31]; keep_dst = &Wv.T[(lane - 15) * 32 + 15]; keep_dst2 = &Wv.Lcol[lane - 16];
+    } else if (lane >= 32 && lane < 48) {
+        const int pl = (lane - 32) >> 3, cy = (lane - 32) & 7;
+        keep_src = &Wv.TC[pl][(cy + 1) * 16 + 15]; keep_dst = &Wv.TC[pl][(cy + 1) * 16 + 7]; keep_dst2 = &Wv.LcolC[pl][cy];
+    }
+    const bool bot_act = lane >= 48 && lane < 56;
+    if (lane >= 48 && lane < 52) { bot_src = &Wv.T[16 * 32 + 16 + (lane - 48) * 4]; bot_dst = &line_y[(lane - 48) * 4]; bot_mul = 16; }
+    else if (lane >= 52 && lane < 54) { bot_src = &Wv.TC[0][8 * 16 + 8 + (lane - 52) * 4]; bot_dst = &line_cb[(lane - 52) * 4]; bot_mul = 8; }
+    else if (lane >= 54 && lane < 56) { bot_src = &Wv.TC[1][8 * 16 + 8 + (lane - 54) * 4]; bot_dst = &line_cr[(lane - 54) * 4]; bot_mul = 8; }
+
     // The packed record is prefetched one macroblock ahead (global -> registers of lanes 0..49,
     // 16 B each = the 800 contiguous bytes), then staged through LDS for the lanes that consume it.
     int4 pre = make_int4(0, 0, 0, 0);
@@ -664,7 +703,11 @@ __global__ __launch_bounds__(NW * 64) void recon_rows_kernel(ReconArgs a)
             for (int c = 0; c < 2; c++) { // derivChromaQP, h264_transform.c:598-637
                 int qpi = qpy + (c ? a.cqp_off_cr : a.cqp_off_cb);
                 qpi = min(max(qpi, 0), 51);
-                qpc[c] = (qpi > 29) ? (int)c_qpc[qpi - 30] : qpi;
+                // Table 8-15 (h264_transform.c:71) as nibbles of (QPC - 29) for qPI = 30..51: scalar arithmetic only
+                const unsigned long long lo = 0x9888776655433210ull, hi = 0xAAAA99ull; // qPI 30..45 | 46..51
+                const int k = qpi - 30;
+                const int nib = (int)(((k < 16) ? (lo >> ((k & 15) * 4)) : (hi >> (((k - 16) & 15) * 4))) & 15ull);
+                qpc[c] = (qpi > 29) ? 29 + nib : qpi;
             }
 
             // Intra16x16 at QP'Y == 36 yields a non-zero DC term even from all-zero levels
@@ -687,15 +730,9 @@ __global__ __launch_bounds__(NW * 64) void recon_rows_kernel(ReconArgs a)
                     }
                 }
                 asm volatile("" ::: "memory");
-                // top neighbours: luma 16 + 8 up-right, chroma 8 + 8
-                if (lane < 4) *reinterpret_cast<uint32_t *>(&Wv.T[16 + lane * 4]) =
-                        *reinterpret_cast<const uint32_t *>(&line_y[mbx * 16 + lane * 4]);
-                else if (lane < 6) { if (C) *reinterpret_cast<uint32_t *>(&Wv.T[32 + (lane - 4) * 4]) =
-                        *reinterpret_cast<const uint32_t *>(&line_y[(mbx + 1) * 16 + (lane - 4) * 4]); }
-                else if (lane < 8) *reinterpret_cast<uint32_t *>(&Wv.TC[0][8 + (lane - 6) * 4]) =
-                        *reinterpret_cast<const uint32_t *>(&line_cb[mbx * 8 + (lane - 6) * 4]);
-                else if (lane < 10) *reinterpret_cast<uint32_t *>(&Wv.TC[1][8 + (lane - 8) * 4]) =
-                        *reinterpret_cast<const uint32_t *>(&line_cr[mbx * 8 + (lane - 8) * 4]);
+                // top neighbours: luma 16 + 8 up-right (when C), chroma 8 + 8
+                if (lane < 10 && (C || (lane >> 1) != 2))
+                    *reinterpret_cast<uint32_t *>(top_dst) = *reinterpret_cast<const uint32_t *>(top_src + mbx * top_mul);
             }
             WAVE_SYNC();
 
@@ -730,28 +767,12 @@ __global__ __launch_bounds__(NW * 64) void recon_rows_kernel(ReconArgs a)
             }
             // ---- neighbour state for the next macroblock / next row ----
             // corners first (old top-right sample), then left columns, then the line buffer.
-            uint32_t keep = 0;
-            if (lane == 0) keep = Wv.T[31];
-            else if (lane == 1) keep = Wv.TC[0][15];
-            else if (lane == 2) keep = Wv.TC[1][15];
-            else if (lane >= 16 && lane < 32) keep = Wv.T[(lane - 16 + 1) * 32 + 31];
-            else if (lane >= 32 && lane < 48) keep = Wv.TC[(lane - 32) >> 3][(((lane - 32) & 7) + 1) * 16 + 15];
-            uint32_t bot = 0;
-            if (lane >= 48 && lane < 52) bot = *reinterpret_cast<const uint32_t *>(&Wv.T[16 * 32 + 16 + (lane - 48) * 4]);
-            else if (lane >= 52 && lane < 54) bot = *reinterpret_cast<const uint32_t *>(&Wv.TC[0][8 * 16 + 8 + (lane - 52) * 4]);
-            else if (lane >= 54 && lane < 56) bot = *reinterpret_cast<const uint32_t *>(&Wv.TC[1][8 * 16 + 8 + (lane - 54) * 4]);
+            uint32_t keep = 0, bot = 0;
+            if (keep_act) keep = *keep_src;
+            if (bot_act) bot = *reinterpret_cast<const uint32_t *>(bot_src);
             WAVE_SYNC();
-            if (lane == 0) Wv.T[15] = (uint8_t)keep;
-            else if (lane == 1) Wv.TC[0][7] = (uint8_t)keep;
-            else if (lane == 2) Wv.TC[1][7] = (uint8_t)keep;
-            else if (lane >= 16 && lane < 32) { Wv.T[(lane - 16 + 1) * 32 + 15] = (uint8_t)keep; Wv.Lcol[lane - 16] = (uint8_t)keep; }
-            else if (lane >= 32 && lane < 48) {
-                const int pl = (lane - 32) >> 3, cy = (lane - 32) & 7;
-                Wv.TC[pl][(cy + 1) * 16 + 7] = (uint8_t)keep; Wv.LcolC[pl][cy] = (uint8_t)keep;
-            }
-            else if (lane >= 48 && lane < 52) *reinterpret_cast<uint32_t *>(&line_y[mbx * 16 + (lane - 48) * 4]) = bot;
-            else if (lane >= 52 && lane < 54) *reinterpret_cast<uint32_t *>(&line_cb[mbx * 8 + (lane - 52) * 4]) = bot;
-            else if (lane >= 54 && lane < 56) *reinterpret_cast<uint32_t *>(&line_cr[mbx * 8 + (lane - 54) * 4]) = bot;
+            if (keep_act) { *keep_dst = (uint8_t)keep; *keep_dst2 = (uint8_t)keep; }
+            if (bot_act) *reinterpret_cast<uint32_t *>(bot_dst + mbx * bot_mul) = bot;
             // ---- publish ----
             done++;
             // LDS operations of one wave complete in order; the explicit wait makes the line-buffer
