@@ -25,7 +25,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
-BYTES_PER_MB_RECON = 800 + 384  # packed record in + planar YCbCr out
+BYTES_PER_MB_RECON = 800 + 384  # SURVEY.md 8(d) B_yuv: packed record in + planar YCbCr out
+BYTES_PER_MB_FUSED = 800 + 384 + 768  # SURVEY.md 8(d) B_rgb: + RGB out written by the fused colour epilogue
 BYTES_PER_MB_COLOR = 384 + 768  # colour kernel: YCbCr in + RGB out (B_rgb - B_yuv = 768 written)
 
 
@@ -40,8 +41,12 @@ def parse_args():
     ap.add_argument("--height-mbs", type=int, default=68)
     ap.add_argument("--profile", default="baseline", choices=["baseline", "high"])
     ap.add_argument("--density", default="dense", choices=["dense", "light"])
+    ap.add_argument("--source", default="stream", choices=["stream", "records"],
+                    help="stream: synthetic Annex-B stream -> host front end -> packed records (default); "
+                         "records: random packed records drawn directly (minivideo_amd.synth)")
     ap.add_argument("--waves", type=int, default=0)
     ap.add_argument("--no-rgb", action="store_true")
+    ap.add_argument("--no-fused", action="store_true", help="run the colour conversion as its own kernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
@@ -88,12 +93,37 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     from minivideo_amd import HotPath
-    from minivideo_amd.synth import synth_packed
 
     want_rgb = not args.no_rgb
     F = args.frames
-    params, rec = synth_packed(args.width_mbs, args.height_mbs, min(args.distinct, F), seed=1000 + rank,
-                               profile=args.profile, density=args.density)
+    n_distinct = min(args.distinct, F)
+    host_rate = None
+    if args.source == "stream":
+        # the real input path: Annex-B bytes -> host entropy decode (CAVLC / CABAC) -> packed records
+        import ctypes as C
+        from minivideo_amd import gen, lib
+        from minivideo_amd.hotpath import StreamParams
+        stream, _ = gen.make_stream(args.width_mbs, args.height_mbs, n_distinct, seed=1000 + rank,
+                                    profile=args.profile, dense=(args.density == "dense"), want_packed=False)
+        L = lib()
+        h = C.c_void_p()
+        if L.mvhp_stream_open(stream.ctypes.data, stream.size, C.byref(h)) != 1:
+            raise SystemExit("bench: the synthetic stream failed to parse")
+        params = StreamParams()
+        L.mvhp_stream_params(h, 0, C.byref(params))
+        rec = np.zeros((n_distinct, params.mbs, 800), np.uint8)
+        t0 = time.perf_counter()
+        for k in range(n_distinct):
+            if L.mvhp_stream_decode_packed(h, k, rec[k].ctypes.data, rec[k].nbytes) != 1:
+                raise SystemExit("bench: host front end failed on picture %d" % k)
+        host_rate = n_distinct * params.mbs / (time.perf_counter() - t0)
+        L.mvhp_stream_close(h)
+        stream_bytes = int(stream.size)
+    else:
+        from minivideo_amd.synth import synth_packed
+        params, rec = synth_packed(args.width_mbs, args.height_mbs, n_distinct, seed=1000 + rank,
+                                   profile=args.profile, density=args.density)
+        stream_bytes = None
     dev = torch.device("cuda", local_rank)
     d_small = torch.from_numpy(rec.reshape(rec.shape[0], -1)).to(dev)
     reps = (F + d_small.shape[0] - 1) // d_small.shape[0]
@@ -105,6 +135,8 @@ def main():
     hot = HotPath(local_rank)
     if args.waves:
         hot.set_waves_per_picture(args.waves)
+    fused = want_rgb and not args.no_fused
+    hot.set_fused_color(fused)
     # a dedicated (non-null) stream: the C-ABI treats a NULL stream as "the context's own stream",
     # and the HIP events below must sit on the stream the kernels are launched on.
     stream = torch.cuda.Stream(device=dev)
@@ -115,10 +147,10 @@ def main():
     def step(ev=None):
         if ev is not None:
             ev[0].record(stream)
-        hot.recon_stages_dev(params, d_packed.data_ptr(), F, d_yuv.data_ptr(), rgb_ptr, sp, 1)
+        hot.recon_stages_dev(params, d_packed.data_ptr(), F, d_yuv.data_ptr(), rgb_ptr, sp, 3 if fused else 1)
         if ev is not None:
             ev[1].record(stream)
-        if want_rgb:
+        if want_rgb and not fused:
             hot.recon_stages_dev(params, d_packed.data_ptr(), F, d_yuv.data_ptr(), rgb_ptr, sp, 2)
         if ev is not None:
             ev[2].record(stream)
@@ -147,7 +179,7 @@ def main():
         elapsed = float(t.item())
 
     ms_recon = float(np.mean([e[0].elapsed_time(e[1]) for e in events]))
-    ms_color = float(np.mean([e[1].elapsed_time(e[2]) for e in events])) if want_rgb else 0.0
+    ms_color = float(np.mean([e[1].elapsed_time(e[2]) for e in events])) if (want_rgb and not fused) else 0.0
 
     mbs_per_step = F * params.mbs
     value = world * mbs_per_step * args.steps / elapsed
@@ -157,14 +189,17 @@ def main():
     if rank == 0:
         from oracle import loader
         yuv0 = d_yuv[: params.yuv_bytes].cpu().numpy()
-        ref, _ = loader.recon(params, rec[:1], 1, want_rgb=False)
+        ref, ref_rgb = loader.recon(params, rec[:1], 1, want_rgb=want_rgb)
         ok = bool(np.array_equal(yuv0, ref))
+        if want_rgb:
+            ok = ok and bool(np.array_equal(d_rgb[: params.rgb_bytes].cpu().numpy(), ref_rgb))
 
     if rank == 0:
         dom_recon = ms_recon >= ms_color
+        bpm = BYTES_PER_MB_FUSED if fused else BYTES_PER_MB_RECON
         if dom_recon:
-            achieved = mbs_per_step * BYTES_PER_MB_RECON / (ms_recon * 1e-3) / 1e9
-            kname = "recon_rows_kernel"
+            achieved = mbs_per_step * bpm / (ms_recon * 1e-3) / 1e9
+            kname = "recon_rows_kernel" + (" (fused RGB epilogue)" if fused else "")
         else:
             achieved = mbs_per_step * BYTES_PER_MB_COLOR / (ms_color * 1e-3) / 1e9
             kname = "ycbcr_to_rgb_kernel"
@@ -180,8 +215,10 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "int32",
-            "data": f"synthetic ({min(args.distinct, F)} distinct random {args.density} pictures tiled to the batch, "
-                    "packed macroblock records resident in HBM)",
+            "data": (f"synthetic ({n_distinct} distinct {args.density} pictures of a generated "
+                     f"{'CAVLC' if args.profile == 'baseline' else 'CABAC'} Annex-B stream, entropy-decoded by the host front end, "
+                     if args.source == "stream" else f"synthetic ({n_distinct} distinct random {args.density} pictures, ")
+                    + "tiled to the batch; packed macroblock records resident in HBM)",
             "config": {
                 "workload": f"{args.width_mbs * 16}x{args.height_mbs * 16} ({args.width_mbs}x{args.height_mbs} MB) "
                             f"{args.profile}-profile IDR pictures, {'4x4 transform only' if args.profile == 'baseline' else '4x4+8x8 transform'}, "
@@ -193,6 +230,9 @@ def main():
                 "bit_exact_vs_oracle": ok,
             },
             "kernel_ms": {"recon_rows_kernel": ms_recon, "ycbcr_to_rgb_kernel": ms_color},
+            "host_frontend": None if host_rate is None else {
+                "macroblocks_per_s_one_thread": host_rate, "stream_bytes_per_picture": stream_bytes / n_distinct,
+                "note": "entropy decode is outside the timed region (inputs resident in HBM)"},
             "roofline": {
                 "bound": "hbm",
                 "kernel": kname,
@@ -201,7 +241,7 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": None,
-                "bytes_per_macroblock": BYTES_PER_MB_RECON if dom_recon else BYTES_PER_MB_COLOR,
+                "bytes_per_macroblock": bpm if dom_recon else BYTES_PER_MB_COLOR,
             },
         }
         if world == 1 and not args.no_cpu_baseline:

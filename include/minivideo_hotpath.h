@@ -162,6 +162,10 @@ MVHP_EXPORT int  mvhp_time_recon(mvhp_ctx_t *ctx, const mvhp_stream_params_t *p,
                                  uint8_t *d_yuv, uint8_t *d_rgb, void *stream,
                                  int iters, float *ms_recon, float *ms_color);
 
+/* 1 (default): the reconstruction kernel converts to RGB in its epilogue when d_rgb is given;
+ * 0: a separate colour kernel reads the planes back.  Speed only, never results. */
+MVHP_EXPORT int  mvhp_set_fused_color(mvhp_ctx_t *ctx, int on);
+
 /* Tuning knob (speed only, never results): waves per picture workgroup
  * (4, 8 or 16); 0 = choose from batch size. */
 MVHP_EXPORT int  mvhp_set_waves_per_picture(mvhp_ctx_t *ctx, int waves);

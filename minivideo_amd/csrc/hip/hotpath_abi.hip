@@ -48,6 +48,7 @@ struct mvhp_ctx {
     hipStream_t  stream;
     uint32_t    *d_err;
     int          waves;       // 0 = auto
+    int          fused_color; // 1 = RGB written by the reconstruction kernel's epilogue (default)
     int          n_cus;
     size_t       max_lds;
     // staging for the host convenience path
@@ -102,6 +103,7 @@ MVHP_EXPORT int mvhp_create(int device, mvhp_ctx_t **out)
     mvhp_ctx *c = new mvhp_ctx();
     memset(c, 0, sizeof(*c));
     c->device = device;
+    c->fused_color = 1;
     c->n_cus = prop.multiProcessorCount;
     c->max_lds = prop.maxSharedMemoryPerMultiProcessor ? prop.maxSharedMemoryPerMultiProcessor : 65536;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
@@ -135,6 +137,13 @@ MVHP_EXPORT int mvhp_set_waves_per_picture(mvhp_ctx_t *c, int waves)
     return MVHP_SUCCESS;
 }
 
+MVHP_EXPORT int mvhp_set_fused_color(mvhp_ctx_t *c, int on)
+{
+    if (!c) return MVHP_FAILURE;
+    c->fused_color = on ? 1 : 0;
+    return MVHP_SUCCESS;
+}
+
 static int pick_waves(const mvhp_ctx *c, const mvhp_stream_params_t *p, int n_frames)
 {
     int nw = c->waves;
@@ -152,6 +161,7 @@ static int launch_all(mvhp_ctx *c, const mvhp_stream_params_t *p, const void *d_
         mvhp::ReconArgs a;
         a.packed = (const uint8_t *)d_packed;
         a.yuv = d_yuv;
+        a.rgb = (c->fused_color && color) ? d_rgb : nullptr;
         a.err = c->d_err;
         a.width_mbs = (int)p->width_mbs;
         a.height_mbs = (int)p->height_mbs;
@@ -164,7 +174,7 @@ static int launch_all(mvhp_ctx *c, const mvhp_stream_params_t *p, const void *d_
         }
         HIP_TRY(mvhp::launch_recon(a, n_frames, nw, st));
     }
-    if (color && d_rgb) {
+    if (color && d_rgb && !(recon && c->fused_color)) {
         mvhp::ColorArgs ca;
         ca.yuv = d_yuv;
         ca.rgb = d_rgb;

@@ -9,6 +9,7 @@ namespace mvhp {
 struct ReconArgs {
     const uint8_t *packed;   // n_frames * W*H * 800 B packed macroblock records
     uint8_t       *yuv;      // n_frames * W*H * 384 B planar Y|Cb|Cr
+    uint8_t       *rgb;      // n_frames * W*H * 768 B RGB8 written by the fused colour epilogue, or NULL
     uint32_t      *err;      // device word: bit0 = dependency wait timed out
     int            width_mbs, height_mbs;
     int            cqp_off_cb, cqp_off_cr;

@@ -40,6 +40,8 @@ struct __attribute__((aligned(16))) WaveLds {
     uint8_t LcolC[2][8];   // compact left neighbour columns (Cb, Cr)
     uint8_t E8[32];        // filtered Intra8x8 edge: [0..1]=rep left7, [2+j]=left[7-j], [10]=corner, [11+i]=top[i], [27]=rep
     int32_t scr[256];      // 8x8 transpose scratch / DC exchange
+    uint8_t SY[16 * 128];  // output strip: 8 macroblocks of reconstructed luma (flushed with wide stores)
+    uint8_t SC[2][8 * 64]; // output strip: 8 macroblocks of Cb / Cr
 };
 
 struct __attribute__((aligned(16))) BlockLds {
@@ -637,6 +639,7 @@ __global__ __launch_bounds__(NW * 64) void recon_rows_kernel(ReconArgs a)
     uint8_t *fy = a.yuv + (size_t)frame * W * H * 384;
     uint8_t *fcb = fy + (size_t)W * H * 256;
     uint8_t *fcr = fcb + (size_t)W * H * 64;
+    uint8_t *frgb = a.rgb ? a.rgb + (size_t)frame * W * H * 768 : nullptr;
     const int pitch = W * 16, cpitch = W * 8;
     const int up_wave = (wave + NW - 1) % NW;
     volatile int *progress = B.progress;
@@ -753,17 +756,67 @@ __global__ __launch_bounds__(NW * 64) void recon_rows_kernel(ReconArgs a)
             // ---- chroma ----
             predict_chroma(Wv, lane, cmode, A, Bv, res_chroma);
 
-            // ---- write-out: planes (coalesced 16-byte luma rows / 8-byte chroma rows) ----
+            // ---- write-out: the macroblock joins an 8-macroblock output strip in LDS; full strips go to HBM
+            //      as 128-byte luma / 64-byte chroma row segments plus (fused) the RGB conversion ----
+            const int mbi = mbx & 7;
             {
                 const int y = lane >> 2, q = lane & 3;
-                *reinterpret_cast<uint32_t *>(&fy[(size_t)(row * 16 + y) * pitch + mbx * 16 + q * 4]) =
+                *reinterpret_cast<uint32_t *>(&Wv.SY[y * 128 + mbi * 16 + q * 4]) =
                     *reinterpret_cast<const uint32_t *>(&Wv.T[(y + 1) * 32 + 16 + q * 4]);
                 if (lane < 32) {
                     const int pl = lane >> 4, cy = (lane & 15) >> 1, hf = lane & 1;
-                    uint8_t *dst = pl ? fcr : fcb;
-                    *reinterpret_cast<uint32_t *>(&dst[(size_t)(row * 8 + cy) * cpitch + mbx * 8 + hf * 4]) =
+                    *reinterpret_cast<uint32_t *>(&Wv.SC[pl][cy * 64 + mbi * 8 + hf * 4]) =
                         *reinterpret_cast<const uint32_t *>(&Wv.TC[pl][(cy + 1) * 16 + 8 + hf * 4]);
                 }
+            }
+            if (mbi == 7 || mbx == W - 1) {
+                WAVE_SYNC();
+                const int x0 = mbx - mbi, nb = (mbi + 1) * 16; // strip origin (MB units), width in samples
+                {   // luma: lane -> 32 bytes of one row
+                    const int y = lane >> 2, part = (lane & 3) * 32;
+                    uint8_t *dst = &fy[(size_t)(row * 16 + y) * pitch + x0 * 16 + part];
+                    if (part < nb) *reinterpret_cast<uint4 *>(dst) = *reinterpret_cast<const uint4 *>(&Wv.SY[y * 128 + part]);
+                    if (part + 16 < nb) *reinterpret_cast<uint4 *>(dst + 16) = *reinterpret_cast<const uint4 *>(&Wv.SY[y * 128 + part + 16]);
+                }
+                {   // chroma: lane -> 16 bytes of one row of one plane
+                    const int pl = lane >> 5, cy = (lane >> 2) & 7, part = (lane & 3) * 16;
+                    uint8_t *dst = (pl ? fcr : fcb) + (size_t)(row * 8 + cy) * cpitch + x0 * 8 + part;
+                    if (part < (nb >> 1)) {
+                        // 8-byte granules: a partial strip may end in the middle of a 16-byte piece
+                        *reinterpret_cast<uint2 *>(dst) = *reinterpret_cast<const uint2 *>(&Wv.SC[pl][cy * 64 + part]);
+                        if (part + 8 < (nb >> 1))
+                            *reinterpret_cast<uint2 *>(dst + 8) = *reinterpret_cast<const uint2 *>(&Wv.SC[pl][cy * 64 + part + 8]);
+                    }
+                }
+                if (frgb) {
+                    // mb_to_rgb (export_utils.c:209-324) on the strip: 2x2 nearest chroma, integer formula :300-302
+                    const int x4 = (lane & 31) * 4;
+                    if (x4 < nb) {
+#pragma unroll 2
+                        for (int i = 0; i < 8; i++) {
+                            const int y = i * 2 + (lane >> 5);
+                            const uint32_t yw = *reinterpret_cast<const uint32_t *>(&Wv.SY[y * 128 + x4]);
+                            const uint32_t cbw = *reinterpret_cast<const uint16_t *>(&Wv.SC[0][(y >> 1) * 64 + (x4 >> 1)]);
+                            const uint32_t crw = *reinterpret_cast<const uint16_t *>(&Wv.SC[1][(y >> 1) * 64 + (x4 >> 1)]);
+                            uint32_t o[12];
+#pragma unroll
+                            for (int q = 0; q < 4; q++) {
+                                const int l = (yw >> (q * 8)) & 255;
+                                const int cb = (cbw >> ((q >> 1) * 8)) & 255, cr = (crw >> ((q >> 1) * 8)) & 255;
+                                const int ly = (298 * l) >> 8;
+                                o[q * 3 + 0] = (uint32_t)clip255(ly + ((408 * cr) >> 8) - 222);
+                                o[q * 3 + 1] = (uint32_t)clip255(ly - ((100 * cb) >> 8) - ((208 * cr) >> 8) + 135);
+                                o[q * 3 + 2] = (uint32_t)clip255(ly + ((516 * cb) >> 8) - 276);
+                            }
+                            uint32_t *dst = reinterpret_cast<uint32_t *>(
+                                frgb + ((size_t)(row * 16 + y) * pitch + x0 * 16 + x4) * 3);
+                            dst[0] = o[0] | (o[1] << 8) | (o[2] << 16) | (o[3] << 24);
+                            dst[1] = o[4] | (o[5] << 8) | (o[6] << 16) | (o[7] << 24);
+                            dst[2] = o[8] | (o[9] << 8) | (o[10] << 16) | (o[11] << 24);
+                        }
+                    }
+                }
+                WAVE_SYNC();
             }
             // ---- neighbour state for the next macroblock / next row ----
             // corners first (old top-right sample), then left columns, then the line buffer.

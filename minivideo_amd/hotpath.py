@@ -71,6 +71,8 @@ def lib():
     L.mvhp_destroy.argtypes = [vp]
     L.mvhp_set_waves_per_picture.restype = i32
     L.mvhp_set_waves_per_picture.argtypes = [vp, i32]
+    L.mvhp_set_fused_color.restype = i32
+    L.mvhp_set_fused_color.argtypes = [vp, i32]
     L.mvhp_recon_batch_dev.restype = i32
     L.mvhp_recon_batch_dev.argtypes = [vp, pp, vp, i32, vp, vp, vp]
     L.mvhp_recon_stages_dev.restype = i32
@@ -126,6 +128,9 @@ class HotPath:
     def set_waves_per_picture(self, waves):
         if self._L.mvhp_set_waves_per_picture(self._h, int(waves)) != SUCCESS:
             raise MiniVideoError("waves per picture must be 0 (auto), 4, 8 or 16")
+
+    def set_fused_color(self, on):
+        self._L.mvhp_set_fused_color(self._h, 1 if on else 0)
 
     # -- host buffers ------------------------------------------------------
     def recon_host(self, params, packed, n_frames, want_rgb=False):
