@@ -35,7 +35,8 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--frames", type=int, default=512, help="pictures per GPU per step")
+    ap.add_argument("--frames", type=int, default=1536, help="pictures per GPU per step (two full rounds of the "
+                    "768 picture-workgroups an MI355X holds at 3 x 8 waves per CU)")
     ap.add_argument("--distinct", type=int, default=16, help="distinct synthetic pictures tiled to --frames")
     ap.add_argument("--width-mbs", type=int, default=120)
     ap.add_argument("--height-mbs", type=int, default=68)

@@ -147,8 +147,9 @@ MVHP_EXPORT int mvhp_set_fused_color(mvhp_ctx_t *c, int on)
 static int pick_waves(const mvhp_ctx *c, const mvhp_stream_params_t *p, int n_frames)
 {
     int nw = c->waves;
-    (void)n_frames;
-    if (nw == 0) nw = 16; // speed only; see DESIGN.md "waves per picture"
+    // speed only (DESIGN.md "waves per picture"): 8-wave workgroups fit three to a CU (LDS) = 24 waves/CU,
+    // 16-wave workgroups one to a CU; small batches need the wider workgroup to occupy the chip.
+    if (nw == 0) nw = (n_frames >= 384) ? 8 : 16;
     while (nw > 4 && (nw / 2) >= (int)p->height_mbs) nw /= 2;
     while (nw > 4 && mvhp::recon_lds_bytes((int)p->width_mbs, nw) > c->max_lds) nw /= 2;
     return nw;

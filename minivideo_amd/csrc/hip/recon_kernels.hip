@@ -40,8 +40,8 @@ struct __attribute__((aligned(16))) WaveLds {
     uint8_t LcolC[2][8];   // compact left neighbour columns (Cb, Cr)
     uint8_t E8[32];        // filtered Intra8x8 edge: [0..1]=rep left7, [2+j]=left[7-j], [10]=corner, [11+i]=top[i], [27]=rep
     int32_t scr[256];      // 8x8 transpose scratch / DC exchange
-    uint8_t SY[16 * 128];  // output strip: 8 macroblocks of reconstructed luma (flushed with wide stores)
-    uint8_t SC[2][8 * 64]; // output strip: 8 macroblocks of Cb / Cr
+    uint8_t SY[16 * 64];   // output strip: 4 macroblocks of reconstructed luma (flushed with wide stores)
+    uint8_t SC[2][8 * 32]; // output strip: 4 macroblocks of Cb / Cr
 };
 
 struct __attribute__((aligned(16))) BlockLds {
@@ -610,7 +610,8 @@ __global__ __launch_bounds__(NW * 64) void recon_rows_kernel(ReconArgs a)
     uint8_t *line_cb = line_y + W * 16;
     uint8_t *line_cr = line_cb + W * 8;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int lane = threadIdx.x & 63;
+    const int lane_c = threadIdx.x & 63;
+    const int lane = lane_c;
     WaveLds &Wv = *reinterpret_cast<WaveLds *>(line_cr + W * 8 + (size_t)wave * sizeof(WaveLds));
     const int frame = blockIdx.x;
 
@@ -683,6 +684,12 @@ __global__ __launch_bounds__(NW * 64) void recon_rows_kernel(ReconArgs a)
         const int up_base = ((wave == 0) ? (pass - 1) : pass) * W; // MBs the upper wave finished before its row (row-1)
         const bool Bv = row > 0;
         for (int mbx = 0; mbx < W; mbx++) {
+            // Re-materialise the lane id every macroblock: it stops the compiler from hoisting hundreds of
+            // lane-dependent LDS addresses out of this loop (128+ VGPRs, 4 waves/SIMD) at the price of a few
+            // recomputed adds (71 VGPRs, 6-7 waves/SIMD).
+            int lane_v = lane_c;
+            asm volatile("" : "+v"(lane_v));
+            const int lane = lane_v;
             if (lane < 50) *reinterpret_cast<int4 *>(&Wv.stage[lane * 16]) = pre;
             {   // next record of this wave: same row, or the first one of its next row
                 int nrow = row, nx = mbx + 1;
@@ -756,48 +763,44 @@ __global__ __launch_bounds__(NW * 64) void recon_rows_kernel(ReconArgs a)
             // ---- chroma ----
             predict_chroma(Wv, lane, cmode, A, Bv, res_chroma);
 
-            // ---- write-out: the macroblock joins an 8-macroblock output strip in LDS; full strips go to HBM
-            //      as 128-byte luma / 64-byte chroma row segments plus (fused) the RGB conversion ----
-            const int mbi = mbx & 7;
+            // ---- write-out: the macroblock joins a 4-macroblock output strip in LDS; full strips go to HBM
+            //      as 64-byte luma / 32-byte chroma row segments plus (fused) the RGB conversion ----
+            const int mbi = mbx & 3;
             {
                 const int y = lane >> 2, q = lane & 3;
-                *reinterpret_cast<uint32_t *>(&Wv.SY[y * 128 + mbi * 16 + q * 4]) =
+                *reinterpret_cast<uint32_t *>(&Wv.SY[y * 64 + mbi * 16 + q * 4]) =
                     *reinterpret_cast<const uint32_t *>(&Wv.T[(y + 1) * 32 + 16 + q * 4]);
                 if (lane < 32) {
                     const int pl = lane >> 4, cy = (lane & 15) >> 1, hf = lane & 1;
-                    *reinterpret_cast<uint32_t *>(&Wv.SC[pl][cy * 64 + mbi * 8 + hf * 4]) =
+                    *reinterpret_cast<uint32_t *>(&Wv.SC[pl][cy * 32 + mbi * 8 + hf * 4]) =
                         *reinterpret_cast<const uint32_t *>(&Wv.TC[pl][(cy + 1) * 16 + 8 + hf * 4]);
                 }
             }
-            if (mbi == 7 || mbx == W - 1) {
+            if (mbi == 3 || mbx == W - 1) {
                 WAVE_SYNC();
                 const int x0 = mbx - mbi, nb = (mbi + 1) * 16; // strip origin (MB units), width in samples
-                {   // luma: lane -> 32 bytes of one row
-                    const int y = lane >> 2, part = (lane & 3) * 32;
-                    uint8_t *dst = &fy[(size_t)(row * 16 + y) * pitch + x0 * 16 + part];
-                    if (part < nb) *reinterpret_cast<uint4 *>(dst) = *reinterpret_cast<const uint4 *>(&Wv.SY[y * 128 + part]);
-                    if (part + 16 < nb) *reinterpret_cast<uint4 *>(dst + 16) = *reinterpret_cast<const uint4 *>(&Wv.SY[y * 128 + part + 16]);
+                {   // luma: lane -> 16 bytes of one row
+                    const int y = lane >> 2, part = (lane & 3) * 16;
+                    if (part < nb)
+                        *reinterpret_cast<uint4 *>(&fy[(size_t)(row * 16 + y) * pitch + x0 * 16 + part]) =
+                            *reinterpret_cast<const uint4 *>(&Wv.SY[y * 64 + part]);
                 }
-                {   // chroma: lane -> 16 bytes of one row of one plane
-                    const int pl = lane >> 5, cy = (lane >> 2) & 7, part = (lane & 3) * 16;
-                    uint8_t *dst = (pl ? fcr : fcb) + (size_t)(row * 8 + cy) * cpitch + x0 * 8 + part;
-                    if (part < (nb >> 1)) {
-                        // 8-byte granules: a partial strip may end in the middle of a 16-byte piece
-                        *reinterpret_cast<uint2 *>(dst) = *reinterpret_cast<const uint2 *>(&Wv.SC[pl][cy * 64 + part]);
-                        if (part + 8 < (nb >> 1))
-                            *reinterpret_cast<uint2 *>(dst + 8) = *reinterpret_cast<const uint2 *>(&Wv.SC[pl][cy * 64 + part + 8]);
-                    }
+                {   // chroma: lane -> 8 bytes of one row of one plane
+                    const int pl = lane >> 5, cy = (lane >> 2) & 7, part = (lane & 3) * 8;
+                    if (part < (nb >> 1))
+                        *reinterpret_cast<uint2 *>((pl ? fcr : fcb) + (size_t)(row * 8 + cy) * cpitch + x0 * 8 + part) =
+                            *reinterpret_cast<const uint2 *>(&Wv.SC[pl][cy * 32 + part]);
                 }
                 if (frgb) {
                     // mb_to_rgb (export_utils.c:209-324) on the strip: 2x2 nearest chroma, integer formula :300-302
-                    const int x4 = (lane & 31) * 4;
+                    const int x4 = (lane & 15) * 4;
                     if (x4 < nb) {
 #pragma unroll 2
-                        for (int i = 0; i < 8; i++) {
-                            const int y = i * 2 + (lane >> 5);
-                            const uint32_t yw = *reinterpret_cast<const uint32_t *>(&Wv.SY[y * 128 + x4]);
-                            const uint32_t cbw = *reinterpret_cast<const uint16_t *>(&Wv.SC[0][(y >> 1) * 64 + (x4 >> 1)]);
-                            const uint32_t crw = *reinterpret_cast<const uint16_t *>(&Wv.SC[1][(y >> 1) * 64 + (x4 >> 1)]);
+                        for (int i = 0; i < 4; i++) {
+                            const int y = i * 4 + (lane >> 4);
+                            const uint32_t yw = *reinterpret_cast<const uint32_t *>(&Wv.SY[y * 64 + x4]);
+                            const uint32_t cbw = *reinterpret_cast<const uint16_t *>(&Wv.SC[0][(y >> 1) * 32 + (x4 >> 1)]);
+                            const uint32_t crw = *reinterpret_cast<const uint16_t *>(&Wv.SC[1][(y >> 1) * 32 + (x4 >> 1)]);
                             uint32_t o[12];
 #pragma unroll
                             for (int q = 0; q < 4; q++) {
