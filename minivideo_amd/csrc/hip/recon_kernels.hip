@@ -378,32 +378,54 @@ __device__ __forceinline__ void predict_mb_4x4(WaveLds &W, const BlockLds &B, in
     constexpr uint32_t REQ = (2u << 0) | (1u << 3) | (0u << 6) | (2u << 9) | (7u << 12) | (7u << 15) | (7u << 18) |
                              (2u << 21) | (1u << 24);
     const int rmask = has_res ? -1 : 0;
+    // Per-block control word, computed once by lane b for block b (16 lanes in parallel) and handed to the
+    // block steps with v_readlane: bits 0-1 left/up available, bit 2 mode is DC, bit 3 prediction allowed,
+    // bits 8.. byte offset of the block's row in the tap table.
+    uint32_t info;
+    {
+        const int b = lane & 15;
+        const uint32_t mw = (b < 4) ? m0 : (b < 8) ? m1 : (b < 12) ? m2 : m3;
+        const uint32_t mode = (mw >> ((b & 3) * 8)) & 255u;
+        const uint32_t avail = ((av.left >> b) & 1u) | (((av.up >> b) & 1u) << 1) | (((av.upleft >> b) & 1u) << 2);
+        const uint32_t req = (REQ >> (min(mode, 8u) * 3)) & 7u;
+        const uint32_t ok = (((req & ~avail) == 0u) && (mode < 9u)) ? 1u : 0u; // else the prediction stays 0 (:442)
+        const uint32_t trow = (((av.upright >> b) & 1u) ? 0u : 9u) + min(mode, 8u);
+        info = (avail & 3u) | ((mode == 2u) ? 4u : 0u) | (ok << 3) | ((trow * 64u) << 8);
+    }
     if (lane < 16) {
         const int pix = (lane >> 2) * 32 + (lane & 3);   // this lane's sample inside a block, tile units
         const int rpix = (lane >> 2) * 16 + (lane & 3);  // same in the residual array
         const uint8_t *T = W.T;
+        const uint8_t *tapb = reinterpret_cast<const uint8_t *>(B.tap4) + lane * 4;
+        // software pipeline: the table entry and the residual of block b+1 are fetched before block b's
+        // dependent tile reads, so only (tile read -> combine -> tile write) sits on the per-block chain
+        uint32_t inf = __builtin_amdgcn_readlane(info, 0);
+        uint32_t e_nx = *reinterpret_cast<const uint32_t *>(tapb + (inf >> 8));
+        int r_nx = (int)W.res[rpix];
 #pragma unroll
         for (int blk = 0; blk < 16; blk++) {
             const int xO = (((blk >> 2) & 1) << 3) | ((blk & 1) << 2);
             const int yO = ((blk >> 3) << 3) | (((blk >> 1) & 1) << 2);
             const int base = (yO + 1) * 32 + 16 + xO;     // tile index of the block's top-left sample
-            const uint32_t mw = (blk < 4) ? m0 : (blk < 8) ? m1 : (blk < 12) ? m2 : m3;
-            const uint32_t mode = (mw >> ((blk & 3) * 8)) & 255u;
-            const uint32_t avail = ((av.left >> blk) & 1u) | (((av.up >> blk) & 1u) << 1) | (((av.upleft >> blk) & 1u) << 2);
-            const int r = (int)W.res[yO * 16 + xO + rpix] & rmask;
+            const uint32_t cur = inf;
+            const uint32_t e = e_nx;
+            const int r = r_nx & rmask;
+            if (blk < 15) {
+                const int nb = blk + 1;
+                const int nxO = (((nb >> 2) & 1) << 3) | ((nb & 1) << 2), nyO = ((nb >> 3) << 3) | (((nb >> 1) & 1) << 2);
+                inf = __builtin_amdgcn_readlane(info, nb);
+                e_nx = *reinterpret_cast<const uint32_t *>(tapb + (inf >> 8));
+                r_nx = (int)W.res[nyO * 16 + nxO + rpix];
+            }
             int pred;
-            if (mode == 2) {
+            if (cur & 4u) { // DC
                 const int sumH = sum4(*reinterpret_cast<const uint32_t *>(&T[base - 32]));
                 const int sumV = T[base - 1] + T[base + 31] + T[base + 63] + T[base + 95];
-                // (avail & 3): 3 both, 1 left only, 2 up only, 0 none
+                const uint32_t lu = cur & 3u; // 3 both, 1 left only, 2 up only, 0 none
                 const int both = (sumH + sumV + 4) >> 3, l = (sumV + 2) >> 2, u = (sumH + 2) >> 2;
-                pred = ((avail & 3u) == 3u) ? both : ((avail & 3u) == 1u) ? l : ((avail & 3u) == 2u) ? u : 128;
+                pred = (lu == 3u) ? both : (lu == 1u) ? l : (lu == 2u) ? u : 128;
             } else {
-                // a mode whose neighbours are missing leaves the prediction at 0 (:442); so does an invalid mode
-                const uint32_t req = (REQ >> (min(mode, 8u) * 3)) & 7u;
-                const int okmask = (((req & ~avail) == 0u) && (mode < 9u)) ? -1 : 0;
-                const uint32_t row = (((av.upright >> blk) & 1u) ? 0u : 9u) + min(mode, 8u);
-                const uint32_t e = B.tap4[row * 16 + lane];
+                const int okmask = (cur & 8u) ? -1 : 0;
                 const int a = T[base - 33 + (int)(e & 255)];
                 const int b = T[base - 33 + (int)((e >> 8) & 255)];
                 const int c = T[base - 33 + (int)(e >> 16)];

@@ -44,7 +44,8 @@ class StreamParams(C.Structure):
 
 
 def lib_path():
-    return os.path.join(_HERE, "libminivideo.so")
+    # MINIVIDEO_LIB: developer override used for A/B experiments with alternative builds of the same library
+    return os.environ.get("MINIVIDEO_LIB") or os.path.join(_HERE, "libminivideo.so")
 
 
 def lib():
