@@ -31,8 +31,7 @@ namespace mvhp {
 // LDS layout
 // ---------------------------------------------------------------------------
 struct __attribute__((aligned(16))) WaveLds {
-    uint8_t stage[MVHP_MB_BYTES]; // the packed record of the macroblock being reconstructed (prefetched one ahead)
-    int16_t res[384];      // residuals, MB raster: luma y*16+x | 256+Cb y*8+x | 320+Cr
+    int16_t res[2][384];   // residuals of a macroblock pair, MB raster: luma y*16+x | 256+Cb y*8+x | 320+Cr
     uint8_t T[17 * 32 + 16]; // luma tile: row 0 = top neighbours; byte 15 = left/corner, 16..31 samples;
                            // row 0 bytes 32..39 = up-right neighbours
     uint8_t TC[2][9 * 16]; // chroma tiles: row 0 = top; byte 7 = left/corner, 8..15 samples
@@ -212,39 +211,56 @@ __device__ __forceinline__ int pack_res(int a, int b)
     return __builtin_bit_cast(int, v);
 }
 
-// Residual stage for one macroblock: fills W.res. Lanes: 4x4 path lane b < 24
-// owns block b (0-15 luma, 16-19 Cb, 20-23 Cr); 8x8 path lanes 0-31 own one
-// row, then one column, of a luma 8x8 block.
-__device__ __forceinline__ void residual_stage(WaveLds &W, const BlockLds &B, const uint8_t *mbp, int lane,
-                                               int kind, int qpy, int qpc_cb, int qpc_cr)
-{
-    const int16_t *coef = reinterpret_cast<const int16_t *>(mbp + MVHP_MB_HEADER_BYTES);
+// Residual stage for a PAIR of horizontally adjacent macroblocks (residuals do not depend on neighbours, so
+// two macroblocks share one pass): lanes 0-23 own the 24 4x4 blocks of macroblock 0, lanes 24-47 those of
+// macroblock 1 (0-15 luma, 16-19 Cb, 20-23 Cr each).  The lane's 16 levels arrive in registers (cA, cB = the
+// two 16-byte halves of its block, prefetched straight from the packed record).  Luma 8x8 blocks: the four
+// lanes of an 8x8 block hold its rows (2i, 2i+1); rows are transformed in place, columns after an LDS transpose.
+struct PairCtl {
+    int kind[2], qpy[2], qpc_cb[2], qpc_cr[2];
+    bool need[2];
+};
 
-    // ---- luma 8x8 (transform_8x8_residual, h264_transform.c:1205-1383) ----
-    if (kind == MVHP_KIND_I8x8) {
+__device__ __forceinline__ void unpack8(const int4 v, int d[8])
+{
+    d[0] = (int16_t)(v.x & 0xffff); d[1] = v.x >> 16; d[2] = (int16_t)(v.y & 0xffff); d[3] = v.y >> 16;
+    d[4] = (int16_t)(v.z & 0xffff); d[5] = v.z >> 16; d[6] = (int16_t)(v.w & 0xffff); d[7] = v.w >> 16;
+}
+
+__device__ __forceinline__ void residual_pair(WaveLds &W, const BlockLds &B, int lane, const int4 cA, const int4 cB,
+                                              const PairCtl &pc)
+{
+    const int sel = (lane >= 24) ? 1 : 0;
+    const int b = lane - 24 * sel; // block index inside the lane's macroblock (valid for lane < 48)
+
+    // ---- luma 8x8 (transform_8x8_residual, h264_transform.c:1205-1383), one macroblock at a time ----
+#pragma unroll
+    for (int s8 = 0; s8 < 2; s8++) {
+        if (pc.kind[s8] != MVHP_KIND_I8x8 || !pc.need[s8]) continue;
+        const int qpy = pc.qpy[s8];
         const int m = qpy % 6, s = qpy / 6;
-        if (lane < 32) {
-            const int blk = lane >> 3, row = lane & 7;
-            const int4 raw = *reinterpret_cast<const int4 *>(coef + blk * 64 + row * 8);
-            int d[8];
-            d[0] = (int16_t)(raw.x & 0xffff); d[1] = raw.x >> 16;
-            d[2] = (int16_t)(raw.y & 0xffff); d[3] = raw.y >> 16;
-            d[4] = (int16_t)(raw.z & 0xffff); d[5] = raw.z >> 16;
-            d[6] = (int16_t)(raw.w & 0xffff); d[7] = raw.w >> 16;
-            if (qpy > 35) {
+        if (lane >= 24 * s8 && lane < 24 * s8 + 16) {
+            const int blk = b >> 2, r0 = (b & 3) * 2;
 #pragma unroll
-                for (int j = 0; j < 8; j++)
-                    d[j] = (int)((unsigned)(d[j] * B.ls8[m * 6 + B.cls8[row * 8 + j]]) << ((s - 6) & 31));
-            } else {
-                const int rnd = 1 << ((5 - s) & 31), sh = (6 - s) & 31;
+            for (int h = 0; h < 2; h++) {
+                const int row = r0 + h;
+                int d[8];
+                unpack8(h ? cB : cA, d);
+                if (qpy > 35) {
 #pragma unroll
-                for (int j = 0; j < 8; j++)
-                    d[j] = (d[j] * B.ls8[m * 6 + B.cls8[row * 8 + j]] + rnd) >> sh;
+                    for (int j = 0; j < 8; j++)
+                        d[j] = (int)((unsigned)(d[j] * B.ls8[m * 6 + B.cls8[row * 8 + j]]) << ((s - 6) & 31));
+                } else {
+                    const int rnd = 1 << ((5 - s) & 31), sh = (6 - s) & 31;
+#pragma unroll
+                    for (int j = 0; j < 8; j++)
+                        d[j] = (d[j] * B.ls8[m * 6 + B.cls8[row * 8 + j]] + rnd) >> sh;
+                }
+                if (row == 0) d[0] += 32; // rounding term of the final (m + 32) >> 6, see idct4x4
+                idct8_1d(d);
+#pragma unroll
+                for (int j = 0; j < 8; j++) W.scr[blk * 64 + row * 8 + j] = d[j];
             }
-            if (row == 0) d[0] += 32; // rounding term of the final (m + 32) >> 6, see idct4x4
-            idct8_1d(d);
-#pragma unroll
-            for (int j = 0; j < 8; j++) W.scr[blk * 64 + row * 8 + j] = d[j];
         }
         WAVE_SYNC();
         if (lane < 32) {
@@ -255,56 +271,58 @@ __device__ __forceinline__ void residual_stage(WaveLds &W, const BlockLds &B, co
             idct8_1d(d);
             const int xO = (blk & 1) * 8, yO = (blk >> 1) * 8;
 #pragma unroll
-            for (int i = 0; i < 8; i++) W.res[(yO + i) * 16 + xO + col] = (int16_t)(pack_res(d[i] >> 6, 0) & 0xffff);
+            for (int i = 0; i < 8; i++)
+                W.res[s8][(yO + i) * 16 + xO + col] = (int16_t)(pack_res(d[i] >> 6, 0) & 0xffff);
         }
         WAVE_SYNC();
     }
 
     // ---- 4x4 blocks (transform_4x4_residual, h264_transform.c:1049-1191) ----
+    const int kind = sel ? pc.kind[1] : pc.kind[0];
+    const int qpy = sel ? pc.qpy[1] : pc.qpy[0];
+    const bool need = sel ? pc.need[1] : pc.need[0];
     const int first = (kind == MVHP_KIND_I8x8) ? 16 : 0;
-    const bool act = (lane >= first) && (lane < 24);
-    const bool all_ge24 = (qpy > 23) && (qpc_cb > 23) && (qpc_cr > 23); // wave-uniform
+    const bool act = (lane < 48) && (b >= first) && need;
+    const bool all_ge24 = (pc.qpy[0] > 23) && (pc.qpc_cb[0] > 23) && (pc.qpc_cr[0] > 23) && (pc.qpy[1] > 23) &&
+                          (pc.qpc_cb[1] > 23) && (pc.qpc_cr[1] > 23); // wave-uniform
     int d[16];
     if (act) {
-        const int4 r0 = *reinterpret_cast<const int4 *>(coef + lane * 16);
-        const int4 r1 = *reinterpret_cast<const int4 *>(coef + lane * 16 + 8);
-        d[0] = (int16_t)(r0.x & 0xffff); d[1] = r0.x >> 16; d[2] = (int16_t)(r0.y & 0xffff); d[3] = r0.y >> 16;
-        d[4] = (int16_t)(r0.z & 0xffff); d[5] = r0.z >> 16; d[6] = (int16_t)(r0.w & 0xffff); d[7] = r0.w >> 16;
-        d[8] = (int16_t)(r1.x & 0xffff); d[9] = r1.x >> 16; d[10] = (int16_t)(r1.y & 0xffff); d[11] = r1.y >> 16;
-        d[12] = (int16_t)(r1.z & 0xffff); d[13] = r1.z >> 16; d[14] = (int16_t)(r1.w & 0xffff); d[15] = r1.w >> 16;
+        unpack8(cA, d);
+        unpack8(cB, d + 8);
         W.scr[lane] = d[0];
     }
     WAVE_SYNC();
     if (act) {
-        const bool chroma = lane >= 16;
-        const int qP = chroma ? ((lane >= 20) ? qpc_cr : qpc_cb) : qpy;
+        const bool chroma = b >= 16;
+        const int qpc = (b >= 20) ? (sel ? pc.qpc_cr[1] : pc.qpc_cr[0]) : (sel ? pc.qpc_cb[1] : pc.qpc_cb[0]);
+        const int qP = chroma ? qpc : qpy;
         const int m = qP % 6, s = qP / 6;
         const int lsA = B.ls4[m * 3 + 0], lsB = B.ls4[m * 3 + 1], lsC = B.ls4[m * 3 + 2];
         int dc = d[0];
         const bool keep_dc = chroma || (kind == MVHP_KIND_I16x16);
         if (chroma) {
             // transform_2x2_chromadc, h264_transform.c:827-860, :924-936, :988-1005
-            const int base = (lane >= 20) ? 20 : 16, k = lane - base;
+            const int base = 24 * sel + ((b >= 20) ? 20 : 16), k = b & 3;
             const int c0 = W.scr[base], c1 = W.scr[base + 1], c2 = W.scr[base + 2], c3 = W.scr[base + 3];
             int f = (k == 0) ? (c0 + c1 + c2 + c3) : (k == 1) ? (c0 - c1 + c2 - c3)
                   : (k == 2) ? (c0 + c1 - c2 - c3) : (c0 - c1 - c2 + c3);
             dc = (int)((unsigned)(f * lsA) << s) >> 5;
         } else if (kind == MVHP_KIND_I16x16) {
             // transform_16x16_lumadc, h264_transform.c:756-812 (incl. the `qP > 36` test)
-            const int bi = ((lane >> 3) << 1) | ((lane >> 1) & 1);   // block row of luma4x4BlkIdx
-            const int bj = (((lane >> 2) & 1) << 1) | (lane & 1);    // block column
+            const int bi = ((b >> 3) << 1) | ((b >> 1) & 1);   // block row of luma4x4BlkIdx
+            const int bj = (((b >> 2) & 1) << 1) | (b & 1);    // block column
             int f = 0;
 #pragma unroll
-            for (int b = 0; b < 16; b++) {
-                const int ri = ((b >> 3) << 1) | ((b >> 1) & 1), rj = (((b >> 2) & 1) << 1) | (b & 1);
-                const int v = W.scr[b];                       // c[ri][rj]
+            for (int q = 0; q < 16; q++) {
+                const int ri = ((q >> 3) << 1) | ((q >> 1) & 1), rj = (((q >> 2) & 1) << 1) | (q & 1);
+                const int v = W.scr[24 * sel + q];            // c[ri][rj]
                 f += (hneg(bi, ri) != hneg(rj, bj)) ? -v : v; // H4[bi][ri] * c * H4[rj][bj]
             }
             if (qpy > 36) dc = (int)((unsigned)(f * lsA) << ((s - 6) & 31));
             else dc = (int)((unsigned)(f * lsA) + (1u << ((5 - s) & 31))) >> ((6 - s) & 31);
         }
-        // quant4x4, h264_transform.c:1100-1134.  qP differs between luma and chroma lanes, so the two
-        // cases are merged: ((c*LS + rnd) >> shr) << shl with (shr, rnd) = (0, 0) when qP > 23.
+        // quant4x4, h264_transform.c:1100-1134.  qP differs between lanes, so the two cases are merged:
+        // ((c*LS + rnd) >> shr) << shl with (shr, rnd) = (0, 0) when qP > 23.
         if (all_ge24) {
             const int shl = s - 4;
 #pragma unroll
@@ -327,19 +345,20 @@ __device__ __forceinline__ void residual_stage(WaveLds &W, const BlockLds &B, co
         idct4x4(d);
         int base, stride;
         if (!chroma) {
-            const int xO = (((lane >> 2) & 1) << 3) | ((lane & 1) << 2);
-            const int yO = ((lane >> 3) << 3) | (((lane >> 1) & 1) << 2);
+            const int xO = (((b >> 2) & 1) << 3) | ((b & 1) << 2);
+            const int yO = ((b >> 3) << 3) | (((b >> 1) & 1) << 2);
             base = yO * 16 + xO; stride = 16;
         } else {
-            const int k = lane & 3;
-            base = 256 + ((lane >= 20) ? 64 : 0) + (k >> 1) * 32 + (k & 1) * 4; stride = 8;
+            const int k = b & 3;
+            base = 256 + ((b >= 20) ? 64 : 0) + (k >> 1) * 32 + (k & 1) * 4; stride = 8;
         }
+        int16_t *res = W.res[sel];
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             int2 pk;
             pk.x = pack_res(d[i * 4 + 0], d[i * 4 + 1]);
             pk.y = pack_res(d[i * 4 + 2], d[i * 4 + 3]);
-            *reinterpret_cast<int2 *>(&W.res[base + i * stride]) = pk;
+            *reinterpret_cast<int2 *>(&res[base + i * stride]) = pk;
         }
     }
     WAVE_SYNC();
@@ -371,7 +390,8 @@ __device__ __forceinline__ Avail4 avail4(bool A, bool Bv, bool C, bool D)
 // Intra 4x4 macroblock: 16 dependent block steps, lanes 0..15 own one sample each.
 // h264_intra_prediction.c:161-177, :315-483, :496-960 + transform4x4_luma (h264_transform.c:121-156).
 __device__ __forceinline__ void predict_mb_4x4(WaveLds &W, const BlockLds &B, int lane, uint32_t m0, uint32_t m1,
-                                               uint32_t m2, uint32_t m3, bool A, bool Bv, bool C, bool D, bool has_res)
+                                               uint32_t m2, uint32_t m3, bool A, bool Bv, bool C, bool D, bool has_res,
+                                               const int16_t *res)
 {
     const Avail4 av = avail4(A, Bv, C, D);
     // neighbours each mode needs, 3 bits per mode: bit0 left, bit1 up, bit2 up-left (mode 2 = DC handled apart)
@@ -401,7 +421,7 @@ __device__ __forceinline__ void predict_mb_4x4(WaveLds &W, const BlockLds &B, in
         // dependent tile reads, so only (tile read -> combine -> tile write) sits on the per-block chain
         uint32_t inf = __builtin_amdgcn_readlane(info, 0);
         uint32_t e_nx = *reinterpret_cast<const uint32_t *>(tapb + (inf >> 8));
-        int r_nx = (int)W.res[rpix];
+        int r_nx = (int)res[rpix];
 #pragma unroll
         for (int blk = 0; blk < 16; blk++) {
             const int xO = (((blk >> 2) & 1) << 3) | ((blk & 1) << 2);
@@ -415,7 +435,7 @@ __device__ __forceinline__ void predict_mb_4x4(WaveLds &W, const BlockLds &B, in
                 const int nxO = (((nb >> 2) & 1) << 3) | ((nb & 1) << 2), nyO = ((nb >> 3) << 3) | (((nb >> 1) & 1) << 2);
                 inf = __builtin_amdgcn_readlane(info, nb);
                 e_nx = *reinterpret_cast<const uint32_t *>(tapb + (inf >> 8));
-                r_nx = (int)W.res[nyO * 16 + nxO + rpix];
+                r_nx = (int)res[nyO * 16 + nxO + rpix];
             }
             int pred;
             if (cur & 4u) { // DC
@@ -441,7 +461,7 @@ __device__ __forceinline__ void predict_mb_4x4(WaveLds &W, const BlockLds &B, in
 // Intra 8x8 block: edge filtering by lanes 0..27, prediction by all 64 lanes.
 // h264_intra_prediction.c:1107-1353 + :1366-1793 + transform8x8_luma.
 __device__ __forceinline__ void predict_8x8(WaveLds &W, const BlockLds &B, int lane, int blk, int mode,
-                                            bool A, bool Bv, bool C, bool D, bool has_res)
+                                            bool A, bool Bv, bool C, bool D, bool has_res, const int16_t *res)
 {
     const int xO = (blk & 1) * 8, yO = (blk >> 1) * 8;
     const bool left = (xO > 0) || A;
@@ -495,14 +515,15 @@ __device__ __forceinline__ void predict_8x8(WaveLds &W, const BlockLds &B, int l
                 pred = (v0 + 2 * v1 + v2 + 2) >> 2;
             }
         }
-        const int r = has_res ? (int)W.res[(yO + y) * 16 + xO + x] : 0;
+        const int r = has_res ? (int)res[(yO + y) * 16 + xO + x] : 0;
         W.T[(yO + y + 1) * 32 + 16 + xO + x] = (uint8_t)clip255(pred + r);
     }
     WAVE_SYNC();
 }
 
 // Intra 16x16: 64 lanes x 4 samples. h264_intra_prediction.c:1809-2141 + transform16x16_luma.
-__device__ __forceinline__ void predict_16x16(WaveLds &W, int lane, int mode, bool A, bool Bv, bool has_res)
+__device__ __forceinline__ void predict_16x16(WaveLds &W, int lane, int mode, bool A, bool Bv, bool has_res,
+                                              const int16_t *res)
 {
     const int y = lane >> 2, x0 = (lane & 3) * 4;
     const bool left = A, up = Bv;
@@ -549,7 +570,7 @@ __device__ __forceinline__ void predict_16x16(WaveLds &W, int lane, int mode, bo
         }
     }
     if (has_res) {
-        const int2 rr = *reinterpret_cast<const int2 *>(&W.res[y * 16 + x0]);
+        const int2 rr = *reinterpret_cast<const int2 *>(&res[y * 16 + x0]);
         p[0] += (int16_t)(rr.x & 0xffff); p[1] += rr.x >> 16;
         p[2] += (int16_t)(rr.y & 0xffff); p[3] += rr.y >> 16;
     }
@@ -561,7 +582,8 @@ __device__ __forceinline__ void predict_16x16(WaveLds &W, int lane, int mode, bo
 
 // Chroma, both planes: lane -> plane = lane>>5, y = (lane&31)>>2, x0 = (lane&3)*2.
 // h264_intra_prediction.c:2157-2564 + transform4x4_chroma.
-__device__ __forceinline__ void predict_chroma(WaveLds &W, int lane, int mode, bool A, bool Bv, bool has_res)
+__device__ __forceinline__ void predict_chroma(WaveLds &W, int lane, int mode, bool A, bool Bv, bool has_res,
+                                               const int16_t *res)
 {
     const int pl = lane >> 5, y = (lane & 31) >> 2, x0 = (lane & 3) * 2;
     const bool left = A, up = Bv;
@@ -611,7 +633,7 @@ __device__ __forceinline__ void predict_chroma(WaveLds &W, int lane, int mode, b
         }
     }
     if (has_res) {
-        const int rr = *reinterpret_cast<const int *>(&W.res[256 + pl * 64 + y * 8 + x0]);
+        const int rr = *reinterpret_cast<const int *>(&res[256 + pl * 64 + y * 8 + x0]);
         p0 += (int16_t)(rr & 0xffff); p1 += rr >> 16;
     }
     const uint16_t out = (uint16_t)(clip255(p0) | (clip255(p1) << 8));
@@ -695,60 +717,95 @@ __global__ __launch_bounds__(NW * 64) void recon_rows_kernel(ReconArgs a)
     else if (lane >= 52 && lane < 54) { bot_src = &Wv.TC[0][8 * 16 + 8 + (lane - 52) * 4]; bot_dst = &line_cb[(lane - 52) * 4]; bot_mul = 8; }
     else if (lane >= 54 && lane < 56) { bot_src = &Wv.TC[1][8 * 16 + 8 + (lane - 54) * 4]; bot_dst = &line_cr[(lane - 54) * 4]; bot_mul = 8; }
 
-    // The packed record is prefetched one macroblock ahead (global -> registers of lanes 0..49,
-    // 16 B each = the 800 contiguous bytes), then staged through LDS for the lanes that consume it.
-    int4 pre = make_int4(0, 0, 0, 0);
-    if (wave < H && lane < 50) pre = *reinterpret_cast<const int4 *>(fpacked + (size_t)(wave * W) * MVHP_MB_BYTES + lane * 16);
+    // Packed records are prefetched one macroblock PAIR ahead, straight into the registers of the lanes that
+    // consume them: lane L < 48 owns 4x4 block (L % 24) of macroblock (L / 24) of the pair = 32 bytes
+    // (pA, pB); lanes 48-51 carry the two 32-byte headers (16 bytes each, pA).  Each 800-byte record is read
+    // exactly once, as two instructions of 16-byte pieces.
+    int4 pA = make_int4(0, 0, 0, 0), pB = make_int4(0, 0, 0, 0);
+    auto prefetch = [&](int prow, int px, int lane_c) {
+        pA = make_int4(0, 0, 0, 0);
+        pB = make_int4(0, 0, 0, 0);
+        if (prow >= H) return;
+        const uint8_t *rec0 = fpacked + (size_t)(prow * W + px) * MVHP_MB_BYTES;
+        const bool two = (px + 1) < W;
+        const uint8_t *src = nullptr;
+        if (lane_c < 24) src = rec0 + MVHP_MB_HEADER_BYTES + lane_c * 32;
+        else if (lane_c < 48) { if (two) src = rec0 + MVHP_MB_BYTES + MVHP_MB_HEADER_BYTES + (lane_c - 24) * 32; }
+        else if (lane_c < 50) src = rec0 + (lane_c - 48) * 16;
+        else if (lane_c < 52) { if (two) src = rec0 + MVHP_MB_BYTES + (lane_c - 50) * 16; }
+        if (src) {
+            pA = *reinterpret_cast<const int4 *>(src);
+            if (lane_c < 48) pB = *reinterpret_cast<const int4 *>(src + 16);
+        }
+    };
+    prefetch(wave, 0, lane_c);
 
     int done = 0; // macroblocks completed by this wave
     for (int row = wave; row < H; row += NW) {
         const int pass = row / NW;
         const int up_base = ((wave == 0) ? (pass - 1) : pass) * W; // MBs the upper wave finished before its row (row-1)
         const bool Bv = row > 0;
-        for (int mbx = 0; mbx < W; mbx++) {
+        for (int mbx0 = 0; mbx0 < W; mbx0 += 2) {
+            const int npair = min(2, W - mbx0);
+            int lane_p = lane_c;
+            asm volatile("" : "+v"(lane_p)); // see the per-macroblock copy below
+            const int4 cA = pA, cB = pB;
+            {   // next pair of this wave: same row, or the first pair of its next row
+                int nrow = row, nx = mbx0 + 2;
+                if (nx >= W) { nrow = row + NW; nx = 0; }
+                prefetch(nrow, nx, lane_p);
+            }
+            // headers: wave-uniform -> scalars (v_readlane from the header lanes)
+            uint32_t hh0[2], hh1[2], hnz[2], hm0[2], hm1[2], hm2[2], hm3[2];
+            PairCtl pc;
+            bool rl[2], rc[2];
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                hh0[k] = __builtin_amdgcn_readlane((uint32_t)cA.x, 48 + 2 * k);
+                hh1[k] = __builtin_amdgcn_readlane((uint32_t)cA.y, 48 + 2 * k);
+                hnz[k] = __builtin_amdgcn_readlane((uint32_t)cA.z, 48 + 2 * k);
+                hm0[k] = __builtin_amdgcn_readlane((uint32_t)cA.w, 48 + 2 * k);
+                hm1[k] = __builtin_amdgcn_readlane((uint32_t)cA.x, 49 + 2 * k);
+                hm2[k] = __builtin_amdgcn_readlane((uint32_t)cA.y, 49 + 2 * k);
+                hm3[k] = __builtin_amdgcn_readlane((uint32_t)cA.z, 49 + 2 * k);
+                pc.kind[k] = hh0[k] & 255;
+                pc.qpy[k] = (hh0[k] >> 8) & 255;
+#pragma unroll
+                for (int c = 0; c < 2; c++) { // derivChromaQP, h264_transform.c:598-637
+                    int qpi = pc.qpy[k] + (c ? a.cqp_off_cr : a.cqp_off_cb);
+                    qpi = min(max(qpi, 0), 51);
+                    // Table 8-15 (h264_transform.c:71) as nibbles of (QPC - 29) for qPI = 30..51: scalar arithmetic only
+                    const unsigned long long lo = 0x9888776655433210ull, hi = 0xAAAA99ull; // qPI 30..45 | 46..51
+                    const int q = qpi - 30;
+                    const int nib = (int)(((q < 16) ? (lo >> ((q & 15) * 4)) : (hi >> (((q - 16) & 15) * 4))) & 15ull);
+                    const int v = (qpi > 29) ? 29 + nib : qpi;
+                    if (c) pc.qpc_cr[k] = v; else pc.qpc_cb[k] = v;
+                }
+                // Intra16x16 at QP'Y == 36 yields a non-zero DC term even from all-zero levels
+                // (h264_transform.c:797-808), so the residual stage cannot be skipped there.
+                const bool quirk36 = (pc.kind[k] == MVHP_KIND_I16x16) && (pc.qpy[k] == 36);
+                rl[k] = ((hnz[k] & 0xffffu) != 0) || quirk36;
+                rc[k] = (hnz[k] & 0xff0000u) != 0;
+                pc.need[k] = (rl[k] || rc[k]) && (k < npair);
+            }
+            if (pc.need[0] || pc.need[1]) residual_pair(Wv, B, lane_p, cA, cB, pc);
+
+#pragma unroll 1
+            for (int k = 0; k < npair; k++) {
+            const int mbx = mbx0 + k;
             // Re-materialise the lane id every macroblock: it stops the compiler from hoisting hundreds of
             // lane-dependent LDS addresses out of this loop (128+ VGPRs, 4 waves/SIMD) at the price of a few
             // recomputed adds (71 VGPRs, 6-7 waves/SIMD).
             int lane_v = lane_c;
             asm volatile("" : "+v"(lane_v));
             const int lane = lane_v;
-            if (lane < 50) *reinterpret_cast<int4 *>(&Wv.stage[lane * 16]) = pre;
-            {   // next record of this wave: same row, or the first one of its next row
-                int nrow = row, nx = mbx + 1;
-                if (nx == W) { nrow = row + NW; nx = 0; }
-                if (nrow < H && lane < 50)
-                    pre = *reinterpret_cast<const int4 *>(fpacked + (size_t)(nrow * W + nx) * MVHP_MB_BYTES + lane * 16);
-            }
-            WAVE_SYNC();
-            const uint8_t *mbp = Wv.stage;
-            const int4 ha = *reinterpret_cast<const int4 *>(mbp), hb = *reinterpret_cast<const int4 *>(mbp + 16);
-            // header: wave-uniform -> scalars
-            const uint32_t h0 = __builtin_amdgcn_readfirstlane((uint32_t)ha.x);
-            const uint32_t h1 = __builtin_amdgcn_readfirstlane((uint32_t)ha.y);
-            const uint32_t nz = __builtin_amdgcn_readfirstlane((uint32_t)ha.z);
-            const int kind = h0 & 255, qpy = (h0 >> 8) & 255;
+            const uint32_t h0 = k ? hh0[1] : hh0[0], h1 = k ? hh1[1] : hh1[0];
+            const uint32_t m0 = k ? hm0[1] : hm0[0], m1 = k ? hm1[1] : hm1[0], m2 = k ? hm2[1] : hm2[0], m3 = k ? hm3[1] : hm3[0];
+            const int kind = h0 & 255;
             const int cmode = (h0 >> 24) & 255, i16mode = h1 & 255;
+            const bool res_luma = k ? rl[1] : rl[0], res_chroma = k ? rc[1] : rc[0];
+            const int16_t *res = Wv.res[k];
             const bool A = mbx > 0, C = Bv && (mbx < W - 1), D = A && Bv;
-
-            int qpc[2];
-#pragma unroll
-            for (int c = 0; c < 2; c++) { // derivChromaQP, h264_transform.c:598-637
-                int qpi = qpy + (c ? a.cqp_off_cr : a.cqp_off_cb);
-                qpi = min(max(qpi, 0), 51);
-                // Table 8-15 (h264_transform.c:71) as nibbles of (QPC - 29) for qPI = 30..51: scalar arithmetic only
-                const unsigned long long lo = 0x9888776655433210ull, hi = 0xAAAA99ull; // qPI 30..45 | 46..51
-                const int k = qpi - 30;
-                const int nib = (int)(((k < 16) ? (lo >> ((k & 15) * 4)) : (hi >> (((k - 16) & 15) * 4))) & 15ull);
-                qpc[c] = (qpi > 29) ? 29 + nib : qpi;
-            }
-
-            // Intra16x16 at QP'Y == 36 yields a non-zero DC term even from all-zero levels
-            // (h264_transform.c:797-808), so the residual stage cannot be skipped there.
-            const bool quirk36 = (kind == MVHP_KIND_I16x16) && (qpy == 36);
-            const bool res_luma = ((nz & 0xffffu) != 0) || quirk36, res_chroma = (nz & 0xff0000u) != 0;
-            if (res_luma || res_chroma) residual_stage(Wv, B, mbp, lane, kind, qpy, qpc[0], qpc[1]);
-            // (when only one of luma/chroma has levels the other half of res holds zeros
-            //  produced by residual_stage from zero coefficients)
 
             // ---- wait for the row above: needs columns <= min(mbx+1, W-1) ----
             if (Bv) {
@@ -770,20 +827,15 @@ __global__ __launch_bounds__(NW * 64) void recon_rows_kernel(ReconArgs a)
 
             // ---- luma ----
             if (kind == MVHP_KIND_I16x16) {
-                predict_16x16(Wv, lane, i16mode, A, Bv, res_luma);
+                predict_16x16(Wv, lane, i16mode, A, Bv, res_luma, res);
             } else if (kind == MVHP_KIND_I4x4) {
-                const uint32_t m0 = __builtin_amdgcn_readfirstlane((uint32_t)ha.w);
-                const uint32_t m1 = __builtin_amdgcn_readfirstlane((uint32_t)hb.x);
-                const uint32_t m2 = __builtin_amdgcn_readfirstlane((uint32_t)hb.y);
-                const uint32_t m3 = __builtin_amdgcn_readfirstlane((uint32_t)hb.z);
-                predict_mb_4x4(Wv, B, lane, m0, m1, m2, m3, A, Bv, C, D, res_luma);
+                predict_mb_4x4(Wv, B, lane, m0, m1, m2, m3, A, Bv, C, D, res_luma, res);
             } else {
-                const uint32_t m0 = __builtin_amdgcn_readfirstlane((uint32_t)ha.w);
                 for (int blk = 0; blk < 4; blk++)
-                    predict_8x8(Wv, B, lane, blk, (m0 >> (blk * 8)) & 255, A, Bv, C, D, res_luma);
+                    predict_8x8(Wv, B, lane, blk, (m0 >> (blk * 8)) & 255, A, Bv, C, D, res_luma, res);
             }
             // ---- chroma ----
-            predict_chroma(Wv, lane, cmode, A, Bv, res_chroma);
+            predict_chroma(Wv, lane, cmode, A, Bv, res_chroma, res);
 
             // ---- write-out: the macroblock joins a 4-macroblock output strip in LDS; full strips go to HBM
             //      as 64-byte luma / 32-byte chroma row segments plus (fused) the RGB conversion ----
@@ -858,6 +910,7 @@ __global__ __launch_bounds__(NW * 64) void recon_rows_kernel(ReconArgs a)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             if (lane == 0) progress[wave] = done;
             WAVE_SYNC();
+            } // macroblock of the pair
         }
     }
 }
