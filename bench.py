@@ -53,6 +53,21 @@ def parse_args():
     return ap.parse_args()
 
 
+def measured_traffic(args, fused, kernel):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes of THIS command
+    (tools/pmc_profile.sh: FETCH_SIZE and WRITE_SIZE in separate passes; FETCH_SIZE doubled per the gfx950
+    correction in MI355X_MICROARCH.md).  Only reported when the run uses the profiled configuration."""
+    path = os.path.join(ROOT, "profiles", "r01_v4_pmc_summary.json")
+    default = (args.frames == 1536 and args.width_mbs == 120 and args.height_mbs == 68 and args.profile == "baseline"
+               and args.density == "dense" and args.source == "stream" and fused and not args.waves)
+    if not (default and os.path.exists(path)):
+        return None, None
+    d = json.load(open(path)).get("recon_rows_kernel" if "recon" in kernel else "ycbcr_to_rgb_kernel", {})
+    if "hbm_read_bytes_corrected" not in d or "hbm_write_bytes" not in d:
+        return None, None
+    return d["hbm_read_bytes_corrected"] + d["hbm_write_bytes"], "profiles/r01_v4_pmc_summary.json"
+
+
 def cpu_baseline(params, rec, want_rgb, budget_s):
     """Time the CPU restatement (oracle/, kind "port") on a bounded sample of the same workload."""
     from oracle import loader
@@ -204,6 +219,7 @@ def main():
         else:
             achieved = mbs_per_step * BYTES_PER_MB_COLOR / (ms_color * 1e-3) / 1e9
             kname = "ycbcr_to_rgb_kernel"
+        traffic, traffic_src = measured_traffic(args, fused, kname)
         out = {
             "metric": "macroblocks/s on 1080p H.264 IDR frames; 1/2/4/8-GPU scaling",
             "value": value,
@@ -241,7 +257,10 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": None if traffic is None else traffic / 1e9,
+                "traffic_unit": "GB per launch (rocprofv3 PMC, separate passes)",
+                "traffic_source": traffic_src,
+                "algorithmic_gb_per_launch": mbs_per_step * (bpm if dom_recon else BYTES_PER_MB_COLOR) / 1e9,
                 "bytes_per_macroblock": bpm if dom_recon else BYTES_PER_MB_COLOR,
             },
         }
