@@ -1,6 +1,9 @@
 // bitreader.h -- MSB-first bit reader over an in-memory RBSP (replaces the
 // file-backed reader of bitstream.c:382-539 and the Exp-Golomb readers of
 // decoder/h264/h264_expgolomb.c:92-172 for the IDR decode path).
+//
+// A 64-bit window is kept left-aligned in `win_`; reads past the end return
+// zero bits and are detected through the bit position (overrun()).
 #pragma once
 #include <stddef.h>
 #include <stdint.h>
@@ -9,8 +12,12 @@ namespace h264 {
 
 class BitReader {
 public:
-    BitReader() : p_(nullptr), n_bits_(0), pos_(0) {}
-    BitReader(const uint8_t *p, size_t n_bytes) : p_(p), n_bits_(n_bytes * 8), pos_(0) {}
+    BitReader() : p_(nullptr), n_bytes_(0), n_bits_(0), pos_(0), win_(0), have_(0), next_(0) {}
+    BitReader(const uint8_t *p, size_t n_bytes)
+        : p_(p), n_bytes_(n_bytes), n_bits_(n_bytes * 8), pos_(0), win_(0), have_(0), next_(0)
+    {
+        refill();
+    }
 
     size_t pos() const { return pos_; }
     size_t size_bits() const { return n_bits_; }
@@ -19,57 +26,47 @@ public:
     bool   byte_aligned() const { return (pos_ & 7) == 0; }
     const uint8_t *data() const { return p_; }
 
-    // Reads past the end return zero bits and set overrun().
-    uint32_t bit()
+    // next n bits (n <= 32) without consuming them; zero-padded past the end
+    uint32_t peek(int n)
     {
-        uint32_t v = 0;
-        if (pos_ < n_bits_) v = (p_[pos_ >> 3] >> (7 - (pos_ & 7))) & 1u;
-        pos_++;
-        return v;
+        if (have_ < n) refill();
+        return n ? (uint32_t)(win_ >> (64 - n)) : 0u;
+    }
+    void skip(size_t n)
+    {
+        pos_ += n;
+        if ((size_t)have_ >= n) { win_ <<= n; have_ -= (int)n; }
+        else reseek();
     }
     uint32_t bits(int n) // n <= 32
     {
-        uint32_t v = 0;
-        if (n > 0 && pos_ + (size_t)n <= n_bits_) {
-            // fast path: gather up to 5 bytes
-            size_t byte = pos_ >> 3;
-            int off = (int)(pos_ & 7);
-            uint64_t acc = 0;
-            int need = (off + n + 7) >> 3;
-            for (int i = 0; i < need; i++) acc = (acc << 8) | p_[byte + i];
-            acc >>= (need * 8 - off - n);
-            v = (uint32_t)(acc & ((n == 32) ? 0xffffffffull : ((1ull << n) - 1)));
-            pos_ += n;
-            return v;
-        }
-        for (int i = 0; i < n; i++) v = (v << 1) | bit();
+        const uint32_t v = peek(n);
+        skip((size_t)n);
         return v;
     }
-    uint32_t peek(int n)
+    uint32_t bit() { return bits(1); }
+    void seek(size_t bitpos) { pos_ = bitpos; reseek(); }
+
+    // number of leading zero bits in the next 32 bits (32 if they are all zero)
+    int leading_zeros32()
     {
-        size_t save = pos_;
-        uint32_t v = bits(n);
-        pos_ = save;
-        return v;
+        const uint32_t v = peek(32);
+        return v ? __builtin_clz(v) : 32;
     }
-    void skip(size_t n) { pos_ += n; }
-    void seek(size_t bitpos) { pos_ = bitpos; }
 
     // ue(v), 9.1 (h264_expgolomb.c:92)
     uint32_t ue()
     {
-        int lz = 0;
-        while (bit() == 0) {
-            if (++lz > 32 || overrun()) return 0xffffffffu;
-        }
+        const int lz = leading_zeros32();
+        if (lz >= 32 || overrun()) { skip(32); return 0xffffffffu; }
+        skip((size_t)lz + 1);
         if (lz == 0) return 0;
-        if (lz == 32) return 0xffffffffu;
         return ((1u << lz) - 1u) + bits(lz);
     }
     // se(v), 9.1.1 (h264_expgolomb.c:107)
     int32_t se()
     {
-        uint32_t k = ue();
+        const uint32_t k = ue();
         if (k == 0xffffffffu) return 0;
         return (k & 1) ? (int32_t)((k + 1) >> 1) : -(int32_t)(k >> 1);
     }
@@ -79,22 +76,43 @@ public:
     bool more_rbsp_data() const
     {
         if (pos_ >= n_bits_) return false;
-        // find last set bit
-        size_t last = n_bits_;
-        size_t nb = n_bits_ >> 3;
+        size_t nb = n_bytes_;
         while (nb > 0 && p_[nb - 1] == 0) nb--;
         if (nb == 0) return false;
-        uint8_t b = p_[nb - 1];
+        const uint8_t b = p_[nb - 1];
         int tz = 0;
         while (((b >> tz) & 1) == 0) tz++;
-        last = (nb - 1) * 8 + (7 - tz); // bit position of the stop bit
+        const size_t last = (nb - 1) * 8 + (size_t)(7 - tz); // bit position of the stop bit
         return pos_ < last;
     }
 
 private:
+    void refill()
+    {
+        while (have_ <= 56) {
+            const uint64_t byte = next_ < n_bytes_ ? p_[next_] : 0;
+            next_++;
+            win_ |= byte << (56 - have_);
+            have_ += 8;
+        }
+    }
+    void reseek()
+    {
+        win_ = 0;
+        have_ = 0;
+        next_ = pos_ >> 3;
+        refill();
+        const int off = (int)(pos_ & 7);
+        win_ <<= off;
+        have_ -= off;
+    }
+
     const uint8_t *p_;
-    size_t n_bits_;
+    size_t n_bytes_, n_bits_;
     size_t pos_;
+    uint64_t win_;
+    int have_;
+    size_t next_;
 };
 
 } // namespace h264

@@ -41,9 +41,10 @@ int CabacEngine::decode_decision(int ctx)
         bin = mps_[ctx];
         state_[ctx] = kTransMps[state_[ctx]];
     }
-    while (range_ < 256) { // RenormD, :2471
-        range_ <<= 1;
-        offset_ = (offset_ << 1) | pd_.br_.bit();
+    if (range_ < 256) { // RenormD, :2471 -- all doublings at once
+        const int sh = __builtin_clz(range_) - 23;
+        range_ <<= sh;
+        offset_ = (offset_ << sh) | pd_.br_.bits(sh);
     }
     return bin;
 }
@@ -59,9 +60,10 @@ int CabacEngine::decode_terminate()
 {
     range_ -= 2;
     if (offset_ >= range_) return 1;
-    while (range_ < 256) {
-        range_ <<= 1;
-        offset_ = (offset_ << 1) | pd_.br_.bit();
+    if (range_ < 256) {
+        const int sh = __builtin_clz(range_) - 23;
+        range_ <<= sh;
+        offset_ = (offset_ << sh) | pd_.br_.bits(sh);
     }
     return 0;
 }

@@ -407,12 +407,11 @@ int PictureDecoder::macroblock(int addr, std::string &err)
     h.i16_pred_mode = (uint8_t)i16_mode;
     memcpy(h.pred_mode, mb.pred, 16);
     uint8_t *rec = out_ + (size_t)addr * MVHP_MB_BYTES;
-    const int16_t *coef = reinterpret_cast<const int16_t *>(rec + MVHP_MB_HEADER_BYTES);
     uint32_t nz = 0;
-    for (int b = 0; b < 24; b++) {
-        bool any = false;
-        for (int i = 0; i < 16; i++) any |= coef[b * 16 + i] != 0;
-        if (any) nz |= 1u << b;
+    for (int b = 0; b < 24; b++) { // 16 levels = four 64-bit words per block
+        uint64_t w[4];
+        memcpy(w, rec + MVHP_MB_HEADER_BYTES + b * 32, 32);
+        if (w[0] | w[1] | w[2] | w[3]) nz |= 1u << b;
     }
     if (mb.kind == MVHP_KIND_I8x8)
         for (int k = 0; k < 4; k++)
@@ -546,14 +545,53 @@ int PictureDecoder::nC_for(int addr, int cat, int blkIdx) const
     return 0;
 }
 
-static int read_vlc(BitReader &br, const uint8_t *len, const uint8_t *code, int n)
-{
-    for (int i = 0; i < n; i++) {
-        if (len[i] == 0) continue;
-        if (br.peek(len[i]) == code[i]) { br.skip(len[i]); return i; }
+// ---- decoding tables built once from the (length, code) tables of h264_tables.h ----
+// coeff_token for 0 <= nC < 8: every code is `lz` zeros, a one, then at most 3 more bits, so the pair
+// (leading zeros, next three bits) identifies it.  Entry: len | total << 8 | trailing_ones << 16 (0 = invalid).
+struct CavlcTables {
+    uint32_t coeff_token[3][17][8];
+    uint16_t total_zeros[15][512];   // index: next 9 bits -> len | value << 8
+    uint8_t  total_zeros_cdc[3][8];  // next 3 bits -> len | value << 4
+    uint8_t  run_before[6][8];       // zerosLeft 1..6: next 3 bits -> len | value << 4
+    CavlcTables()
+    {
+        memset(this, 0, sizeof(*this));
+        for (int tab = 0; tab < 3; tab++)
+            for (int t = 0; t < 4; t++)
+                for (int n = 0; n < 17; n++) {
+                    const int len = kCoeffTokenLen[tab][t][n], code = kCoeffTokenCode[tab][t][n];
+                    if (!len) continue;
+                    int width = 0;
+                    while ((code >> width) != 0) width++;        // position of the leading one
+                    const int lz = len - width, sfx = width - 1; // bits after the one
+                    const int sfx_bits = code & ((1 << sfx) - 1);
+                    for (int fill = 0; fill < (1 << (3 - sfx)); fill++)
+                        coeff_token[tab][lz][(sfx_bits << (3 - sfx)) | fill] = (uint32_t)len | (n << 8) | (t << 16);
+                }
+        for (int v = 0; v < 15; v++)
+            for (int z = 0; z < 16; z++) {
+                const int len = kTotalZerosLen[v][z], code = kTotalZerosCode[v][z];
+                if (!len) continue;
+                for (int fill = 0; fill < (1 << (9 - len)); fill++)
+                    total_zeros[v][(code << (9 - len)) | fill] = (uint16_t)(len | (z << 8));
+            }
+        for (int v = 0; v < 3; v++)
+            for (int z = 0; z < 4; z++) {
+                const int len = kTotalZerosChromaDcLen[v][z], code = kTotalZerosChromaDcCode[v][z];
+                if (!len) continue;
+                for (int fill = 0; fill < (1 << (3 - len)); fill++)
+                    total_zeros_cdc[v][(code << (3 - len)) | fill] = (uint8_t)(len | (z << 4));
+            }
+        for (int v = 0; v < 6; v++)
+            for (int r = 0; r < 15; r++) {
+                const int len = kRunBeforeLen[v][r], code = kRunBeforeCode[v][r];
+                if (!len) continue;
+                for (int fill = 0; fill < (1 << (3 - len)); fill++)
+                    run_before[v][(code << (3 - len)) | fill] = (uint8_t)(len | (r << 4));
+            }
     }
-    return -1;
-}
+};
+static const CavlcTables g_cavlc;
 
 int PictureDecoder::residual_block_cavlc(int addr, int *coeffLevel, int startIdx, int endIdx, int maxNumCoeff, int cat,
                                          int blkIdx)
@@ -574,11 +612,11 @@ int PictureDecoder::residual_block_cavlc(int addr, int *coeffLevel, int startIdx
             }
     } else {
         const int tab = nC < 2 ? 0 : (nC < 4 ? 1 : 2);
-        for (int t = 0; t < 4 && total < 0; t++)
-            for (int n = 0; n < 17; n++) {
-                const int l = kCoeffTokenLen[tab][t][n];
-                if (l && br_.peek(l) == kCoeffTokenCode[tab][t][n]) { br_.skip(l); total = n; t1s = t; break; }
-            }
+        const int lz = br_.leading_zeros32();
+        if (lz <= 16) {
+            const uint32_t e = g_cavlc.coeff_token[tab][lz][(br_.peek(lz + 4) & 7u)];
+            if (e) { br_.skip(e & 255u); total = (int)((e >> 8) & 255u); t1s = (int)(e >> 16); }
+        }
     }
     if (total < 0) return RC_FAILURE;
     // h264_cavlc.c:207-212: the count is recorded for neighbours (luma categories share tc_luma;
@@ -595,10 +633,9 @@ int PictureDecoder::residual_block_cavlc(int addr, int *coeffLevel, int startIdx
         if (i < t1s) {
             level[i] = 1 - 2 * (int)br_.bit();
         } else {
-            int level_prefix = 0;
-            while (br_.bit() == 0) {
-                if (++level_prefix > 32 || br_.overrun()) return RC_FAILURE;
-            }
+            const int level_prefix = br_.leading_zeros32();
+            if (level_prefix > 28 || br_.overrun()) return RC_FAILURE;
+            br_.skip((size_t)level_prefix + 1);
             int levelCode = (level_prefix < 15 ? level_prefix : 15) << suffixLength;
             if (suffixLength > 0 || level_prefix >= 14) {
                 int size = suffixLength;
@@ -617,18 +654,37 @@ int PictureDecoder::residual_block_cavlc(int addr, int *coeffLevel, int startIdx
     int zerosLeft = 0;
     if (total < endIdx - startIdx + 1) {
         int tz;
-        if (cat == CAT_CHROMA_DC_CB || cat == CAT_CHROMA_DC_CR)
-            tz = read_vlc(br_, kTotalZerosChromaDcLen[total - 1], kTotalZerosChromaDcCode[total - 1], 4);
-        else
-            tz = read_vlc(br_, kTotalZerosLen[total - 1], kTotalZerosCode[total - 1], 16);
-        if (tz < 0) return RC_FAILURE;
+        if (cat == CAT_CHROMA_DC_CB || cat == CAT_CHROMA_DC_CR) {
+            const uint8_t e = g_cavlc.total_zeros_cdc[total - 1][br_.peek(3)];
+            if (!e) return RC_FAILURE;
+            br_.skip(e & 15u);
+            tz = e >> 4;
+        } else {
+            const uint16_t e = g_cavlc.total_zeros[total - 1][br_.peek(9)];
+            if (!e) return RC_FAILURE;
+            br_.skip(e & 255u);
+            tz = e >> 8;
+        }
         zerosLeft = tz;
     }
     for (int i = 0; i < total - 1; i++) {
         if (zerosLeft > 0) {
-            const int v = (zerosLeft - 1 < 6) ? zerosLeft - 1 : 6;
-            const int rb = read_vlc(br_, kRunBeforeLen[v], kRunBeforeCode[v], 15);
-            if (rb < 0) return RC_FAILURE;
+            int rb;
+            if (zerosLeft <= 6) {
+                const uint8_t e = g_cavlc.run_before[zerosLeft - 1][br_.peek(3)];
+                if (!e) return RC_FAILURE;
+                br_.skip(e & 15u);
+                rb = e >> 4;
+            } else { // Table 9-10, zerosLeft > 6: 3-bit codes 111..001 = 0..6, then 0001 = 7, 00001 = 8, ...
+                const uint32_t v3 = br_.peek(3);
+                if (v3) { br_.skip(3); rb = 7 - (int)v3; }
+                else {
+                    const int lz = br_.leading_zeros32();
+                    if (lz > 10) return RC_FAILURE;
+                    br_.skip((size_t)lz + 1);
+                    rb = lz + 4;
+                }
+            }
             run[i] = rb;
         } else {
             run[i] = 0;
