@@ -144,6 +144,10 @@ MVHP_EXPORT int  mvhp_recon_stages_dev(mvhp_ctx_t *ctx, const mvhp_stream_params
                                        const void *d_packed, int n_frames,
                                        uint8_t *d_yuv, uint8_t *d_rgb, void *stream, int stages);
 
+/* Page-locked host memory for the host-buffer entry points (H2D / D2H at full PCIe rate). */
+MVHP_EXPORT void *mvhp_host_alloc(size_t bytes);
+MVHP_EXPORT void  mvhp_host_free(void *p);
+
 /* Wait for `stream` (NULL = context stream) and report any error the kernels
  * flagged since the last check. */
 MVHP_EXPORT int  mvhp_sync_check(mvhp_ctx_t *ctx, void *stream);

@@ -137,6 +137,21 @@ MVHP_EXPORT int mvhp_set_waves_per_picture(mvhp_ctx_t *c, int waves)
     return MVHP_SUCCESS;
 }
 
+MVHP_EXPORT void *mvhp_host_alloc(size_t bytes)
+{
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) {
+        set_err("hipHostMalloc(%zu) failed", bytes);
+        return nullptr;
+    }
+    return p;
+}
+
+MVHP_EXPORT void mvhp_host_free(void *p)
+{
+    if (p) (void)hipHostFree(p);
+}
+
 MVHP_EXPORT int mvhp_set_fused_color(mvhp_ctx_t *c, int on)
 {
     if (!c) return MVHP_FAILURE;

@@ -163,16 +163,38 @@ std::vector<int> select_idrs(const mvhp_stream &s, int picture_number, int mode)
 }
 
 // ---- frame-level work queue over host threads and HIP devices ----
+// A Window is a run of consecutive pictures processed together: their packed records, planes and RGB live in
+// three page-locked buffers (recycled between windows), so entropy threads write records in place, each device
+// DMA-reads its share and DMA-writes results in place, and the writer streams files straight from the buffer.
 struct Picture {
     int idr = -1;
     int rc = h264::RC_FAILURE;
     std::string err;
     mvhp_stream_params_t params{};
-    std::vector<uint8_t> packed, yuv, rgb;
+    size_t packed_off = 0, yuv_off = 0, rgb_off = 0;
 };
 
 struct Window {
     std::vector<Picture> pics;
+    uint8_t *packed = nullptr, *yuv = nullptr, *rgb = nullptr;
+    size_t packed_cap = 0, yuv_cap = 0, rgb_cap = 0;
+    ~Window()
+    {
+        mvhp_host_free(packed);
+        mvhp_host_free(yuv);
+        mvhp_host_free(rgb);
+    }
+    bool reserve(size_t pb, size_t yb, size_t rb)
+    {
+        auto grow = [](uint8_t *&p, size_t &cap, size_t need) {
+            if (need <= cap) return true;
+            mvhp_host_free(p);
+            p = (uint8_t *)mvhp_host_alloc(need);
+            cap = p ? need : 0;
+            return p != nullptr;
+        };
+        return grow(packed, packed_cap, pb) && grow(yuv, yuv_cap, yb) && (rb == 0 || grow(rgb, rgb_cap, rb));
+    }
 };
 
 template <class F> void parallel_for(int n, int threads, F f)
@@ -216,6 +238,7 @@ public:
             if (mvhp_create(d, &c) != MVHP_SUCCESS) { err = mvhp_last_error(); return false; }
             ctx_.push_back(c);
         }
+        for (int i = 0; i < 3; i++) free_.push_back(std::make_unique<Window>());
         entropy_thread_ = std::thread([this] { entropy_stage(); });
         gpu_thread_ = std::thread([this] { gpu_stage(); });
         return true;
@@ -238,17 +261,24 @@ public:
         if (done_.empty()) return nullptr;
         auto w = std::move(done_.front());
         done_.pop_front();
-        l.unlock();
-        cv_.notify_all();
         return w;
+    }
+    // hand a consumed window's buffers back
+    void recycle(std::unique_ptr<Window> w)
+    {
+        {
+            std::lock_guard<std::mutex> l(mu_);
+            free_.push_back(std::move(w));
+        }
+        cv_.notify_all();
     }
 
 private:
     int window_frames(const mvhp_stream_params_t &p) const
     {
         const size_t pb = mvhp_packed_frame_bytes(&p);
-        long f = (long)((size_t)384 << 20) / (long)(pb ? pb : 1);
-        if (f < n_gpus_) f = n_gpus_;
+        long f = (long)((size_t)256 << 20) / (long)(pb ? pb : 1);
+        if (f < 2 * n_gpus_) f = 2 * n_gpus_;
         if (f < 4) f = 4;
         if (f > 256) f = 256;
         return (int)f;
@@ -257,30 +287,49 @@ private:
     {
         size_t pos = 0;
         while (pos < order_.size()) {
+            std::unique_ptr<Window> w;
+            {
+                std::unique_lock<std::mutex> l(mu_);
+                cv_.wait(l, [this] { return stop_ || !free_.empty(); });
+                if (stop_) break;
+                w = std::move(free_.front());
+                free_.pop_front();
+            }
             mvhp_stream_params_t p0{};
             int wf = 16;
             for (size_t k = pos; k < order_.size(); k++)
                 if (mvhp_stream_params(&s_, order_[k], &p0) == MVHP_SUCCESS) { wf = window_frames(p0); break; }
-            auto w = std::make_unique<Window>();
             const size_t end = std::min(order_.size(), pos + (size_t)wf);
-            w->pics.resize(end - pos);
-            for (size_t k = pos; k < end; k++) w->pics[k - pos].idr = order_[k];
-            parallel_for((int)w->pics.size(), host_threads_, [&](int i) {
-                Picture &pic = w->pics[i];
+            w->pics.assign(end - pos, Picture());
+            size_t pb = 0, yb = 0, rb = 0;
+            for (size_t k = pos; k < end; k++) {
+                Picture &pic = w->pics[k - pos];
+                pic.idr = order_[k];
                 if (mvhp_stream_params(&s_, pic.idr, &pic.params) != MVHP_SUCCESS) {
                     pic.rc = h264::RC_FAILURE;
                     pic.err = "parameter sets missing";
-                    return;
+                    continue;
                 }
-                pic.packed.resize(mvhp_packed_frame_bytes(&pic.params));
-                pic.rc = s_.decode_packed(pic.idr, pic.packed.data(), pic.packed.size(), pic.err);
-            });
+                pic.rc = h264::RC_UNSUPPORTED; // "not parsed yet"
+                pic.packed_off = pb; pic.yuv_off = yb; pic.rgb_off = rb;
+                pb += mvhp_packed_frame_bytes(&pic.params);
+                yb += mvhp_yuv_frame_bytes(&pic.params);
+                if (want_rgb_) rb += mvhp_rgb_frame_bytes(&pic.params);
+            }
+            if (!w->reserve(pb, yb, rb)) {
+                for (Picture &pic : w->pics) { pic.rc = h264::RC_FAILURE; pic.err = "out of page-locked host memory"; }
+            } else {
+                parallel_for((int)w->pics.size(), host_threads_, [&](int i) {
+                    Picture &pic = w->pics[i];
+                    if (pic.rc != h264::RC_UNSUPPORTED) return;
+                    pic.rc = s_.decode_packed(pic.idr, w->packed + pic.packed_off, mvhp_packed_frame_bytes(&pic.params), pic.err);
+                });
+            }
             pos = end;
-            std::unique_lock<std::mutex> l(mu_);
-            cv_.wait(l, [this] { return stop_ || parsed_.size() < 2; });
-            if (stop_) break;
-            parsed_.push_back(std::move(w));
-            l.unlock();
+            {
+                std::lock_guard<std::mutex> l(mu_);
+                parsed_.push_back(std::move(w));
+            }
             cv_.notify_all();
         }
         {
@@ -300,34 +349,25 @@ private:
                 w = std::move(parsed_.front());
                 parsed_.pop_front();
             }
-            cv_.notify_all();
-            // pictures that parsed, in runs of identical stream parameters, dealt out to the devices
-            std::vector<int> ok;
-            for (int i = 0; i < (int)w->pics.size(); i++) if (w->pics[i].rc == h264::RC_SUCCESS) ok.push_back(i);
-            size_t a = 0;
-            while (a < ok.size()) {
-                size_t b = a + 1;
-                while (b < ok.size() && same_params(w->pics[ok[a]].params, w->pics[ok[b]].params)) b++;
-                const int n = (int)(b - a);
+            // maximal runs of consecutive parsed pictures with identical stream parameters are contiguous in the
+            // window buffers; each run is dealt out to the devices in contiguous shares
+            const int n_pics = (int)w->pics.size();
+            int a = 0;
+            while (a < n_pics) {
+                if (w->pics[a].rc != h264::RC_SUCCESS) { a++; continue; }
+                int b = a + 1;
+                while (b < n_pics && w->pics[b].rc == h264::RC_SUCCESS && same_params(w->pics[a].params, w->pics[b].params)) b++;
+                const int n = b - a;
                 const int parts = std::min(n, n_gpus_);
                 std::atomic<int> next_part(0);
                 auto work = [&](int dev) {
                     for (int part; (part = next_part.fetch_add(1)) < parts;) {
-                        const int lo = (int)((long)n * part / parts), hi = (int)((long)n * (part + 1) / parts);
-                        const mvhp_stream_params_t &p = w->pics[ok[a + lo]].params;
-                        const size_t pb = mvhp_packed_frame_bytes(&p), yb = mvhp_yuv_frame_bytes(&p), rb = mvhp_rgb_frame_bytes(&p);
-                        std::vector<uint8_t> packed((size_t)(hi - lo) * pb), yuv((size_t)(hi - lo) * yb), rgb;
-                        if (want_rgb_) rgb.resize((size_t)(hi - lo) * rb);
-                        for (int i = lo; i < hi; i++) memcpy(&packed[(size_t)(i - lo) * pb], w->pics[ok[a + i]].packed.data(), pb);
-                        const int rc = mvhp_recon_batch_host(ctx_[dev], &p, packed.data(), hi - lo, yuv.data(),
-                                                             want_rgb_ ? rgb.data() : nullptr);
-                        for (int i = lo; i < hi; i++) {
-                            Picture &pic = w->pics[ok[a + i]];
-                            if (rc != MVHP_SUCCESS) { pic.rc = h264::RC_FAILURE; pic.err = mvhp_last_error(); continue; }
-                            pic.yuv.assign(&yuv[(size_t)(i - lo) * yb], &yuv[(size_t)(i - lo + 1) * yb]);
-                            if (want_rgb_) pic.rgb.assign(&rgb[(size_t)(i - lo) * rb], &rgb[(size_t)(i - lo + 1) * rb]);
-                            std::vector<uint8_t>().swap(pic.packed);
-                        }
+                        const int lo = a + (int)((long)n * part / parts), hi = a + (int)((long)n * (part + 1) / parts);
+                        const Picture &first = w->pics[lo];
+                        const int rc = mvhp_recon_batch_host(ctx_[dev], &first.params, w->packed + first.packed_off, hi - lo,
+                                                             w->yuv + first.yuv_off, want_rgb_ ? w->rgb + first.rgb_off : nullptr);
+                        if (rc != MVHP_SUCCESS)
+                            for (int i = lo; i < hi; i++) { w->pics[i].rc = h264::RC_FAILURE; w->pics[i].err = mvhp_last_error(); }
                     }
                 };
                 std::vector<std::thread> th;
@@ -337,9 +377,7 @@ private:
                 a = b;
             }
             {
-                std::unique_lock<std::mutex> l(mu_);
-                cv_.wait(l, [this] { return stop_ || done_.size() < 2; });
-                if (stop_) break;
+                std::lock_guard<std::mutex> l(mu_);
                 done_.push_back(std::move(w));
             }
             cv_.notify_all();
@@ -359,7 +397,7 @@ private:
     std::thread entropy_thread_, gpu_thread_;
     std::mutex mu_;
     std::condition_variable cv_;
-    std::deque<std::unique_ptr<Window>> parsed_, done_;
+    std::deque<std::unique_ptr<Window>> free_, parsed_, done_;
     bool stop_ = false, entropy_finished_ = false, gpu_finished_ = false;
 };
 
@@ -521,15 +559,17 @@ minivideo_EXPORT int minivideo_decode(MediaFile_t *m, const char *output_directo
             name += ext;
             const int W = (int)pic.params.width_mbs * 16, H = (int)pic.params.height_mbs * 16;
             int ok = 0;
-            if (fmt == PICTURE_PNG) ok = mvexport::write_png(name, pic.rgb.data(), W, H);
-            else if (fmt == PICTURE_BMP) ok = mvexport::write_bmp(name, pic.rgb.data(), W, H);
-            else if (fmt == PICTURE_TGA) ok = mvexport::write_tga(name, pic.rgb.data(), W, H);
-            else if (fmt == PICTURE_YUV444) ok = mvexport::write_yuv444(name, pic.yuv.data(), W, H);
-            else ok = mvexport::write_yuv420(name, pic.yuv.data(), W, H);
+            const uint8_t *yuv = w->yuv + pic.yuv_off, *rgb = want_rgb ? w->rgb + pic.rgb_off : nullptr;
+            if (fmt == PICTURE_PNG) ok = mvexport::write_png(name, rgb, W, H);
+            else if (fmt == PICTURE_BMP) ok = mvexport::write_bmp(name, rgb, W, H);
+            else if (fmt == PICTURE_TGA) ok = mvexport::write_tga(name, rgb, W, H);
+            else if (fmt == PICTURE_YUV444) ok = mvexport::write_yuv444(name, yuv, W, H);
+            else ok = mvexport::write_yuv420(name, yuv, W, H);
             if (!ok) { log_err("Unable to write '%s'", name.c_str()); errors++; continue; }
             exported++;
             if (exported == wanted) { retcode = SUCCESS; running = false; break; } // h264.c:173-179
         }
+        if (running) pipe.recycle(std::move(w));
     }
     pipe.stop();
     if (retcode != SUCCESS && exported > 0 && errors <= 64) retcode = SUCCESS; // stream ended after the last good IDR
