@@ -13,8 +13,9 @@
  *   - minivideo_decode() writes <input basename>[_k].<ext> into the CURRENT WORKING
  *     DIRECTORY and ignores output_directory (export.c:627-642,704-708, h264.c:65);
  *   - no deblocking filter is applied; the picture is the uncropped coded size;
- *   - H.264 IDR pictures only (Annex-B elementary streams: .264/.h264 or a file
- *     starting with an SPS start code).
+ *   - H.264 IDR pictures only, from Annex-B elementary streams (.264/.h264 or a
+ *     file starting with an SPS start code) or from the first H.264 video track
+ *     of an MP4/MOV file (demuxer/mp4/mp4.c:1950 mp4_fileParse -> sync samples).
  * Differences: reconstruction runs on HIP devices (there is no CPU
  * reconstruction path: without a GPU minivideo_decode() returns FAILURE);
  * invalid streams return FAILURE instead of calling exit().

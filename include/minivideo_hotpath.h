@@ -109,6 +109,9 @@ typedef struct mvhp_stream mvhp_stream_t;   /* parsed elementary stream */
 /* Index + parse parameter sets of an Annex-B buffer held in memory.
  * The buffer must outlive the handle. */
 MVHP_EXPORT int  mvhp_stream_open(const uint8_t *data, size_t size, mvhp_stream_t **out);
+/* Same for an ISO-BMFF (MP4/MOV) buffer: avcC parameter sets + the IDR NAL units of the sync samples of the first
+ * video track (replaces demuxer/mp4/mp4.c:2587 mp4_fileParse for the thumbnail path). */
+MVHP_EXPORT int  mvhp_stream_open_mp4(const uint8_t *data, size_t size, mvhp_stream_t **out);
 MVHP_EXPORT void mvhp_stream_close(mvhp_stream_t *s);
 MVHP_EXPORT int  mvhp_stream_idr_count(const mvhp_stream_t *s);
 /* Parameters in force for IDR picture `idr` (valid after mvhp_stream_open). */

@@ -28,6 +28,7 @@
 #include "h264_frontend.h"
 #include "minivideo.h"
 #include "minivideo_hotpath.h"
+#include "mp4_demux.h"
 #include "stream_internal.h"
 
 namespace {
@@ -127,6 +128,51 @@ bool read_whole_file(MediaFile_t *m, std::vector<uint8_t> &buf)
     const size_t n = fread(buf.data(), 1, buf.size(), m->file_pointer);
     rewind(m->file_pointer);
     return n == buf.size();
+}
+
+// ---- MP4: public sample map as convertTrack builds it (demuxer/mp4/mp4.c:150-500): the avcC parameter sets first,
+//      then every sample of the video track, sync samples marked ----
+int parse_mp4_track(MediaFile_t *m, const std::vector<uint8_t> &buf)
+{
+    mp4::VideoTrack trk;
+    std::string err;
+    if (!mp4::parse(buf.data(), buf.size(), trk, err)) { log_err("%s", err.c_str()); return FAILURE; }
+    free_map(&m->tracks_video[0]);
+    BitstreamMap_t *map = (BitstreamMap_t *)calloc(1, sizeof(BitstreamMap_t));
+    if (!map) return FAILURE;
+    const size_t n = trk.sps.size() + trk.pps.size() + trk.samples.size();
+    map->sample_type = (uint32_t *)calloc(n, sizeof(uint32_t));
+    map->sample_size = (uint32_t *)calloc(n, sizeof(uint32_t));
+    map->sample_offset = (int64_t *)calloc(n, sizeof(int64_t));
+    map->sample_pts = (int64_t *)calloc(n, sizeof(int64_t));
+    map->sample_dts = (int64_t *)calloc(n, sizeof(int64_t));
+    if (!map->sample_type || !map->sample_size || !map->sample_offset || !map->sample_pts || !map->sample_dts) {
+        free_map(&map);
+        return FAILURE;
+    }
+    map->stream_type = stream_VIDEO;
+    map->stream_codec = CODEC_H264;
+    map->stream_fcc = 0x61766331u; // 'avc1'
+    map->sample_alignment = true;
+    map->width = trk.width;
+    map->height = trk.height;
+    if (trk.timescale) map->duration_ms = (unsigned int)((double)trk.duration / (double)trk.timescale * 1000.0);
+    size_t k = 0;
+    for (const mp4::NalRef &r : trk.sps) { map->sample_type[k] = sample_VIDEO_PARAM; map->sample_offset[k] = (int64_t)r.offset; map->sample_size[k] = (uint32_t)r.size; map->sample_pts[k] = map->sample_dts[k] = -1; k++; }
+    for (const mp4::NalRef &r : trk.pps) { map->sample_type[k] = sample_VIDEO_PARAM; map->sample_offset[k] = (int64_t)r.offset; map->sample_size[k] = (uint32_t)r.size; map->sample_pts[k] = map->sample_dts[k] = -1; k++; }
+    for (const mp4::Sample &sm : trk.samples) {
+        map->sample_type[k] = sm.sync ? sample_VIDEO_SYNC : sample_VIDEO;
+        map->sample_offset[k] = (int64_t)sm.offset;
+        map->sample_size[k] = (uint32_t)sm.size;
+        map->stream_size += sm.size;
+        if (sm.sync) map->frame_count_idr++;
+        k++;
+    }
+    map->sample_count = (uint32_t)n;
+    map->frame_count = (uint32_t)trk.samples.size();
+    m->tracks_video[0] = map;
+    m->tracks_video_count = 1;
+    return SUCCESS;
 }
 
 // ---- demuxer/filter.c:52-215: which IDR samples to decode, in which order ----
@@ -457,13 +503,14 @@ minivideo_EXPORT int minivideo_parse(MediaFile_t *m, const bool extract_audio, c
     (void)extract_audio; (void)extract_video; (void)extract_subtitles;
     if (!m) { log_err("Unable to parse NULL MediaFile_t struct!"); return FAILURE; }
     if (m->file_size == 0) { log_err("Unable to parse emtpy file!"); return FAILURE; }
-    if (m->container != CONTAINER_ES) {
-        log_err("Unable to parse container format '%s': only H.264 elementary streams are handled by this build",
+    if (m->container != CONTAINER_ES && m->container != CONTAINER_MP4) {
+        log_err("Unable to parse container format '%s': only H.264 elementary streams and MP4/MOV are handled by this build",
                 getContainerString(m->container, false));
         return FAILURE;
     }
     std::vector<uint8_t> buf;
     if (!read_whole_file(m, buf)) { log_err("Unable to read the media file"); return FAILURE; }
+    if (m->container == CONTAINER_MP4) return parse_mp4_track(m, buf);
     std::vector<h264::EsSample> samples;
     if (h264::index_annexb(buf.data(), buf.size(), samples) != h264::RC_SUCCESS) {
         log_err("No NAL Unit have been found in this bitstream!");
@@ -518,7 +565,8 @@ minivideo_EXPORT int minivideo_decode(MediaFile_t *m, const char *output_directo
     s.data = buf.data();
     s.size = buf.size();
     std::string err;
-    if (s.build(err) != h264::RC_SUCCESS) { log_err("%s", err.c_str()); return FAILURE; }
+    const int brc = (m->container == CONTAINER_MP4) ? s.build_mp4(err) : s.build(err);
+    if (brc != h264::RC_SUCCESS) { log_err("%s", err.c_str()); return FAILURE; }
 
     // idr_filtering (filter.c:52-92)
     int wanted = picture_number;

@@ -7,6 +7,7 @@
 #include <vector>
 
 #include "h264_frontend.h"
+#include "mp4_demux.h"
 #include "stream_internal.h"
 
 using namespace h264;
@@ -50,6 +51,71 @@ int mvhp_stream::build(std::string &err)
     return RC_SUCCESS;
 }
 
+// MP4: parameter sets come from the avcC box, pictures from the sync samples of the first
+// video track; a sample is a sequence of length-prefixed NAL units.  The decode target is "the same pictures as the
+// elementary-stream path" -- in-band SPS/PPS are honoured, the first IDR slice NAL of a sync sample is the picture.
+int mvhp_stream::build_mp4(std::string &err)
+{
+    mp4::VideoTrack trk;
+    if (!mp4::parse(data, size, trk, err)) return RC_FAILURE;
+    Sps sps_tab[32];
+    Pps pps_tab[256];
+    std::vector<uint8_t> rbsp;
+    auto add_param = [&](size_t off, size_t len) {
+        if (len < 2 || off + len > size) return;
+        const int type = data[off] & 31;
+        unescape_rbsp(data + off + 1, len - 1, rbsp);
+        BitReader br(rbsp.data(), rbsp.size());
+        std::string e;
+        if (type == 7) { Sps sps; if (parse_sps(br, sps, e) == RC_SUCCESS) sps_tab[sps.sps_id] = sps; else param_errors++; }
+        else if (type == 8) { Pps pps; if (parse_pps(br, sps_tab, pps, e) == RC_SUCCESS) pps_tab[pps.pps_id] = pps; else param_errors++; }
+    };
+    for (const mp4::NalRef &n : trk.sps) add_param(n.offset, n.size);
+    for (const mp4::NalRef &n : trk.pps) add_param(n.offset, n.size);
+    for (const mp4::Sample &smp : trk.samples) {
+        if (!smp.sync || smp.size == 0) continue;
+        size_t p = smp.offset;
+        const size_t end = smp.offset + smp.size;
+        bool took = false;
+        while (p + (size_t)trk.nal_length_size < end) {
+            size_t len = 0;
+            for (int i = 0; i < trk.nal_length_size; i++) len = (len << 8) | data[p + i];
+            p += (size_t)trk.nal_length_size;
+            if (len == 0 || len > end - p) break;
+            const int type = data[p] & 31;
+            if (type == 7 || type == 8) add_param(p, len);
+            else if (type == 5 && !took) {
+                EsSample s;
+                s.offset = p;
+                s.sample_size = s.nal_size = len;
+                s.nal_unit_type = 5;
+                s.nal_ref_idc = (data[p] >> 5) & 3;
+                s.is_idr = true;
+                samples.push_back(s);
+                Idr idr;
+                idr.sample = samples.size() - 1;
+                unescape_rbsp(data + p + 1, len - 1 < 16 ? len - 1 : 16, rbsp);
+                BitReader br(rbsp.data(), rbsp.size());
+                br.ue();
+                br.ue();
+                const unsigned pid = br.ue();
+                if (pid < 256 && pps_tab[pid].valid && sps_tab[pps_tab[pid].sps_id].valid) {
+                    idr.pps = pps_tab[pid];
+                    idr.sps = sps_tab[idr.pps.sps_id];
+                    idr.ok = true;
+                } else {
+                    idr.why = "slice refers to a parameter set that was not (successfully) received";
+                }
+                idrs.push_back(idr);
+                took = true;
+            }
+            p += len;
+        }
+    }
+    if (idrs.empty()) { err = "MP4: no IDR picture in the sync samples"; return RC_FAILURE; }
+    return RC_SUCCESS;
+}
+
 int mvhp_stream::decode_packed(int k, void *packed, size_t bytes, std::string &err) const
 {
     if (k < 0 || (size_t)k >= idrs.size()) { err = "IDR index out of range"; return RC_FAILURE; }
@@ -76,6 +142,18 @@ MVHP_EXPORT int mvhp_stream_open(const uint8_t *data, size_t size, mvhp_stream_t
     s->data = data;
     s->size = size;
     if (s->build(g_stream_err) != RC_SUCCESS) { delete s; return MVHP_FAILURE; }
+    *out = s;
+    return MVHP_SUCCESS;
+}
+
+MVHP_EXPORT int mvhp_stream_open_mp4(const uint8_t *data, size_t size, mvhp_stream_t **out)
+{
+    if (!out || !data) return MVHP_FAILURE;
+    *out = nullptr;
+    mvhp_stream *s = new mvhp_stream();
+    s->data = data;
+    s->size = size;
+    if (s->build_mp4(g_stream_err) != RC_SUCCESS) { delete s; return MVHP_FAILURE; }
     *out = s;
     return MVHP_SUCCESS;
 }

@@ -19,6 +19,7 @@ struct mvhp_stream {
     std::vector<Idr> idrs;
     int param_errors = 0;
 
-    int build(std::string &err);
+    int build(std::string &err);      // Annex-B elementary stream
+    int build_mp4(std::string &err);  // ISO-BMFF: avcC parameter sets + length-prefixed NAL units of the sync samples
     int decode_packed(int idr, void *packed, size_t bytes, std::string &err) const;
 };

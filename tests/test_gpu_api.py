@@ -112,6 +112,17 @@ def test_cli_yuv420_multi(tmp_path, profile):
         assert np.array_equal(got, exp[k][0]), k
 
 
+def test_cli_mp4_equals_es(tmp_path):
+    from tests.mp4mux import mux
+    W, H, F = 12, 9, 4
+    stream, packed = gen.make_stream(W, H, F, seed=37, profile="high")
+    data = np.frombuffer(mux(stream, W * 16, H * 16, extra_non_sync=True, samples_per_chunk=3), np.uint8)
+    _run(tmp_path, data, "clip.mp4", "-f", "yuv420", "-n", str(F))
+    exp = _expected(W, H, packed)
+    for k in range(F):
+        assert np.array_equal(np.fromfile(tmp_path / f"clip_{k}.yuv", np.uint8), exp[k][0]), k
+
+
 def test_cli_single_picture_name_and_full_hd(tmp_path):
     stream, packed = gen.make_stream(120, 68, 2, seed=32, profile="baseline")
     _run(tmp_path, stream, "movie.h264", "-f", "yuv420")       # -n 1: no _k suffix (export.c:630-642)

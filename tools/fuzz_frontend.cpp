@@ -1,7 +1,7 @@
 // tools/fuzz_frontend.cpp -- sanitizer harness for the host front end (CPU only):
 //   g++ -O1 -g -fsanitize=address,undefined -std=c++17 -Iinclude -Iminivideo_amd/csrc/host \
-//       tools/fuzz_frontend.cpp minivideo_amd/csrc/host/{h264_frontend,h264_cabac,stream_abi}.cpp -o /tmp/fuzz_frontend
-//   /tmp/fuzz_frontend stream.264 [iterations]
+//       tools/fuzz_frontend.cpp minivideo_amd/csrc/host/{h264_frontend,h264_cabac,stream_abi,mp4_demux}.cpp -o /tmp/fuzz_frontend
+//   /tmp/fuzz_frontend stream.264|clip.mp4 [iterations]      (a .mp4/.mov name goes through mvhp_stream_open_mp4)
 // Mutates the stream (bit flips, byte splats, truncations) and parses every picture; any memory error aborts.
 #include <stdio.h>
 #include <stdlib.h>
@@ -30,6 +30,8 @@ int main(int argc, char **argv)
     size_t n;
     while ((n = fread(buf, 1, sizeof(buf), f)) > 0) base.insert(base.end(), buf, buf + n);
     fclose(f);
+    const size_t nl = strlen(argv[1]);
+    const bool is_mp4 = nl > 4 && (!strcmp(argv[1] + nl - 4, ".mp4") || !strcmp(argv[1] + nl - 4, ".mov"));
     const int iters = argc > 2 ? atoi(argv[2]) : 2000;
     long ok = 0, bad = 0;
     for (int it = 0; it < iters; it++) {
@@ -44,7 +46,7 @@ int main(int argc, char **argv)
             else { d.resize(pos + 1); d.insert(d.end(), 64, 0); break; }
         }
         mvhp_stream_t *s = nullptr;
-        if (mvhp_stream_open(d.data(), d.size(), &s) != MVHP_SUCCESS) continue;
+        if ((is_mp4 ? mvhp_stream_open_mp4(d.data(), d.size(), &s) : mvhp_stream_open(d.data(), d.size(), &s)) != MVHP_SUCCESS) continue;
         const int cnt = mvhp_stream_idr_count(s);
         for (int k = 0; k < cnt; k++) {
             mvhp_stream_params_t p;
