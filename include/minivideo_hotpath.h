@@ -177,6 +177,15 @@ MVHP_EXPORT int  mvhp_set_fused_color(mvhp_ctx_t *ctx, int on);
  * (4, 8 or 16); 0 = choose from batch size. */
 MVHP_EXPORT int  mvhp_set_waves_per_picture(mvhp_ctx_t *ctx, int waves);
 
+/* Tuning knob (speed only, never results): how pictures map onto workgroups.
+ * MVHP_LAYOUT_ROWS: one picture per workgroup, one wavefront per macroblock row (fills the chip from
+ * ~256 pictures); MVHP_LAYOUT_QUAD: four pictures per workgroup, 16 lanes per picture (fewer
+ * instructions per macroblock, wants >= ~1024 pictures); MVHP_LAYOUT_AUTO chooses from the batch size. */
+#define MVHP_LAYOUT_AUTO 0
+#define MVHP_LAYOUT_ROWS 1
+#define MVHP_LAYOUT_QUAD 2
+MVHP_EXPORT int  mvhp_set_layout(mvhp_ctx_t *ctx, int layout);
+
 #ifdef __cplusplus
 }
 #endif

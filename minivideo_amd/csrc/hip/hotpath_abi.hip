@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "minivideo_hotpath.h"
@@ -48,6 +49,7 @@ struct mvhp_ctx {
     hipStream_t  stream;
     uint32_t    *d_err;
     int          waves;       // 0 = auto
+    int          layout;      // MVHP_LAYOUT_*
     int          fused_color; // 1 = RGB written by the reconstruction kernel's epilogue (default)
     int          n_cus;
     size_t       max_lds;
@@ -104,6 +106,10 @@ MVHP_EXPORT int mvhp_create(int device, mvhp_ctx_t **out)
     memset(c, 0, sizeof(*c));
     c->device = device;
     c->fused_color = 1;
+    if (const char *e = getenv("MINIVIDEO_LAYOUT")) { // tuning / test override, speed only
+        if (!strcmp(e, "rows")) c->layout = MVHP_LAYOUT_ROWS;
+        else if (!strcmp(e, "quad")) c->layout = MVHP_LAYOUT_QUAD;
+    }
     c->n_cus = prop.multiProcessorCount;
     c->max_lds = prop.maxSharedMemoryPerMultiProcessor ? prop.maxSharedMemoryPerMultiProcessor : 65536;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
@@ -137,6 +143,13 @@ MVHP_EXPORT int mvhp_set_waves_per_picture(mvhp_ctx_t *c, int waves)
     return MVHP_SUCCESS;
 }
 
+MVHP_EXPORT int mvhp_set_layout(mvhp_ctx_t *c, int layout)
+{
+    if (!c || layout < MVHP_LAYOUT_AUTO || layout > MVHP_LAYOUT_QUAD) return MVHP_FAILURE;
+    c->layout = layout;
+    return MVHP_SUCCESS;
+}
+
 MVHP_EXPORT void *mvhp_host_alloc(size_t bytes)
 {
     void *p = nullptr;
@@ -159,9 +172,24 @@ MVHP_EXPORT int mvhp_set_fused_color(mvhp_ctx_t *c, int on)
     return MVHP_SUCCESS;
 }
 
-static int pick_waves(const mvhp_ctx *c, const mvhp_stream_params_t *p, int n_frames)
+static bool pick_quad(const mvhp_ctx *c, int n_frames)
+{
+    if (c->layout == MVHP_LAYOUT_QUAD) return true;
+    if (c->layout == MVHP_LAYOUT_ROWS) return false;
+    // speed only: four pictures per workgroup needs 4 * CUs pictures before every CU has work
+    return n_frames >= 4 * c->n_cus;
+}
+
+static int pick_waves(const mvhp_ctx *c, const mvhp_stream_params_t *p, int n_frames, bool quad)
 {
     int nw = c->waves;
+    if (quad) {
+        // speed only: 8-wave workgroups fit two to a CU (LDS); small batches take the wider workgroup
+        if (nw == 0) nw = (n_frames >= 8 * c->n_cus) ? 8 : 16;
+        while (nw > 4 && (nw / 2) >= (int)p->height_mbs) nw /= 2;
+        while (nw > 4 && mvhp::recon_quad_lds_bytes((int)p->width_mbs, nw) > c->max_lds) nw /= 2;
+        return nw;
+    }
     // speed only (DESIGN.md "waves per picture"): 8-wave workgroups fit three to a CU (LDS) = 24 waves/CU,
     // 16-wave workgroups one to a CU; small batches need the wider workgroup to occupy the chip.
     if (nw == 0) nw = (n_frames >= 384) ? 8 : 16;
@@ -183,12 +211,19 @@ static int launch_all(mvhp_ctx *c, const mvhp_stream_params_t *p, const void *d_
         a.height_mbs = (int)p->height_mbs;
         a.cqp_off_cb = p->chroma_qp_index_offset;
         a.cqp_off_cr = p->second_chroma_qp_index_offset;
-        const int nw = pick_waves(c, p, n_frames);
-        if (mvhp::recon_lds_bytes(a.width_mbs, nw) > c->max_lds) {
-            set_err("picture too wide for the LDS line buffer (%u macroblocks)", p->width_mbs);
-            return MVHP_UNSUPPORTED;
+        a.n_frames = n_frames;
+        bool quad = pick_quad(c, n_frames);
+        if (quad && mvhp::recon_quad_lds_bytes(a.width_mbs, 4) > c->max_lds) quad = false; // four line buffers do not fit
+        const int nw = pick_waves(c, p, n_frames, quad);
+        if (quad) {
+            HIP_TRY(mvhp::launch_recon_quad(a, nw, st));
+        } else {
+            if (mvhp::recon_lds_bytes(a.width_mbs, nw) > c->max_lds) {
+                set_err("picture too wide for the LDS line buffer (%u macroblocks)", p->width_mbs);
+                return MVHP_UNSUPPORTED;
+            }
+            HIP_TRY(mvhp::launch_recon(a, n_frames, nw, st));
         }
-        HIP_TRY(mvhp::launch_recon(a, n_frames, nw, st));
     }
     if (color && d_rgb && !(recon && c->fused_color)) {
         mvhp::ColorArgs ca;

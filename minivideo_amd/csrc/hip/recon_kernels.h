@@ -13,6 +13,7 @@ struct ReconArgs {
     uint32_t      *err;      // device word: bit0 = dependency wait timed out
     int            width_mbs, height_mbs;
     int            cqp_off_cb, cqp_off_cr;
+    int            n_frames;
 };
 
 struct ColorArgs {
@@ -23,6 +24,9 @@ struct ColorArgs {
 
 size_t     recon_lds_bytes(int width_mbs, int nw);
 hipError_t launch_recon(const ReconArgs &a, int n_frames, int nw, hipStream_t stream);
+// four pictures per workgroup, 16 lanes per picture (recon_quad.hip)
+size_t     recon_quad_lds_bytes(int width_mbs, int nw);
+hipError_t launch_recon_quad(const ReconArgs &a, int nw, hipStream_t stream);
 hipError_t launch_color(const ColorArgs &a, hipStream_t stream);
 
 } // namespace mvhp

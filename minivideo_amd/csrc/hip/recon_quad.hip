@@ -1,0 +1,761 @@
+// recon_quad.hip -- the batch form of the reconstruction kernel (gfx950 only).
+//
+//   recon_quad_kernel<NW>   same contract as recon_rows_kernel (recon_kernels.hip): replaces
+//                           intra_prediction_process() (decoder/h264/h264_intra_prediction.c:112-145),
+//                           all of h264_transform.c, the planar gather of export.c:65-188 and
+//                           mb_to_rgb() (export_utils.c:209-324) for whole pictures.
+//
+// Mapping: one workgroup reconstructs FOUR pictures in lockstep.  A wavefront is split into four
+// quarters of 16 lanes, quarter q works on picture 4*blockIdx+q; wave w owns macroblock rows
+// w, w+NW, ... of all four.  The four pictures sit at the same macroblock position at any time, so
+// everything positional (neighbour availability, the row-above dependency wait, addresses inside a
+// picture) is wave-uniform, while everything the stream decides (macroblock kind, prediction modes,
+// QP, coefficients) is per-lane data.  The reason: the Intra4x4 chain is 16 dependent block steps of
+// 16 samples each -- with one picture per wavefront 48 of the 64 lanes idle through it, and every
+// instruction is paid per wavefront, not per lane.  Here each step serves four macroblocks.
+//
+// Inside a quarter, lane j owns luma 4x4 block j (luma4x4BlkIdx order) and, for j < 8, chroma block j
+// (0-3 Cb, 4-7 Cr): its 16 levels arrive in registers straight from the packed record, are dequantised
+// and inverse-transformed there, and for Intra16x16 / chroma the same lane predicts its 16 samples and
+// writes them to the tile -- the residual never touches LDS.  Only Intra4x4 / Intra8x8 residuals are
+// transposed through LDS (lane-per-block -> lane-per-sample).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "minivideo_hotpath.h"
+#include "recon_kernels.h"
+#include "recon_device.h"
+
+namespace mvhp {
+
+// per-quarter (= per-picture, per-wave) LDS state
+struct __attribute__((aligned(16))) QLds {
+    union {
+        int32_t scr[128];    // Intra8x8: two 8x8 blocks of row-transformed coefficients (transpose scratch)
+        int16_t res[256];    // Intra4x4: [blk][sample] ; Intra8x8: [blk8][column][row]
+    };
+    uint8_t T[17 * 32 + 16]; // luma tile: row 0 = top neighbours; byte 15 = left/corner, 16..31 samples;
+                             // row 0 bytes 32..39 = up-right neighbours
+    uint8_t TC[2][9 * 16];   // chroma tiles: row 0 = top; byte 7 = left/corner, 8..15 samples
+    uint8_t Lcol[16];        // compact left neighbour column (luma)
+    uint8_t LcolC[2][8];     // compact left neighbour columns (Cb, Cr)
+    uint8_t E8[32];          // filtered Intra8x8 edge, see recon_device.h mode_entry()
+    uint8_t pad[16];         // 1440 B: quarters land 360 dwords apart (different banks)
+};
+static_assert(sizeof(QLds) == 1440, "QLds layout");
+
+struct __attribute__((aligned(16))) QTables {
+    int      progress[16];   // macroblocks completed by wave w (monotonic over its rows)
+    int      abort_flag;
+    int      pad[3];
+    int4     q4[52];         // per qP: LevelScale4x4 classes (0,0) (1,1) (other), pre-shifted left by max(qP/6-4,0);
+                             // w = shr | rnd << 8 | (qP/6) << 16 | (qP%6) << 24, shr = max(4-qP/6,0), rnd = (1<<shr)>>1
+    int      ls0[52];        // LevelScale4x4(qP%6,0,0), unshifted (DC transforms)
+    int      ls8[36];        // LevelScale8x8 classes (h264.c:438-446)
+    uint8_t  qpc[64];        // Table 8-15 (h264_transform.c:71): qPI -> QPc
+    uint32_t tap4[2 * 9 * 16];
+    uint32_t tap8[9 * 64];
+};
+
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ int pk_add_sat(int a, int b)
+{
+    return __builtin_bit_cast(int, __builtin_elementwise_add_sat(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b)));
+}
+// two int16 -> two uint8 with unsigned saturation, in the low 16 bits
+__device__ __forceinline__ uint32_t sat_pk_u8(int v)
+{
+    uint32_t o;
+    asm("v_sat_pk_u8_i16 %0, %1" : "=v"(o) : "v"(v));
+    return o;
+}
+
+// Prediction (four row words of four samples) + residual (eight packed int16 pairs) -> tile.
+__device__ __forceinline__ void emit_block(uint8_t *dst, int pitch, const uint32_t pw[4], const int r2[8])
+{
+#pragma unroll
+    for (int y = 0; y < 4; y++) {
+        const int lo = (int)__builtin_amdgcn_perm(0u, pw[y], 0x0c010c00u);
+        const int hi = (int)__builtin_amdgcn_perm(0u, pw[y], 0x0c030c02u);
+        const uint32_t a = sat_pk_u8(pk_add_sat(lo, r2[2 * y]));
+        const uint32_t b = sat_pk_u8(pk_add_sat(hi, r2[2 * y + 1]));
+        *reinterpret_cast<uint32_t *>(dst + y * pitch) = a | (b << 16);
+    }
+}
+
+// Four plane-prediction samples clip255((v + k*b) >> 5), k = 0..3, as one row word (v_ashr_pk_u8_i32 shifts,
+// saturates to 0..255 and packs two samples).
+__device__ __forceinline__ uint32_t plane_row(int v, int b)
+{
+    const uint32_t lo = (uint16_t)__builtin_amdgcn_ashr_pk_u8_i32(v, v + b, 5);
+    const uint32_t hi = (uint16_t)__builtin_amdgcn_ashr_pk_u8_i32(v + 2 * b, v + 3 * b, 5);
+    return lo | (hi << 16);
+}
+
+// quad_perm DPP controls
+#define DPP_XOR1 0xB1  // [1,0,3,2]
+#define DPP_XOR2 0x4E  // [2,3,0,1]
+template <int CTRL>
+__device__ __forceinline__ int dpp_quad(int v)
+{
+    return __builtin_amdgcn_mov_dpp(v, CTRL, 0xf, 0xf, true);
+}
+// value of lane k of this lane's quarter (qbase4 = byte address of the quarter's lane 0 = (lane & 48) * 4)
+__device__ __forceinline__ uint32_t quarter_bcast(uint32_t v, int qbase4, int k)
+{
+    return (uint32_t)__builtin_amdgcn_ds_bpermute(qbase4 + k * 4, (int)v);
+}
+
+// 4-point transform with the matrix of h264_transform.c:62-68 (rows ++++, ++--, +--+, +-+-) across four
+// lanes: `p` = the value of the lane whose index differs in the low index bit, then the lanes holding the
+// pair sums / differences are fetched with ds_bpermute.  idx = this lane's index along the dimension.
+__device__ __forceinline__ int had4_lanes(int x, int p, int idx, int addrP, int addrQ)
+{
+    const int t = (idx & 1) ? (p - x) : (x + p);       // idx 0: a = x0+x1, 1: b = x0-x1, 2: c = x2+x3, 3: e = x2-x3
+    const int P = __builtin_amdgcn_ds_bpermute(addrP, t);
+    const int Q = __builtin_amdgcn_ds_bpermute(addrQ, t);
+    return (idx == 1 || idx == 2) ? (P - Q) : (P + Q); // a+c, a-c, b-e, b+e
+}
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void recon_quad_kernel(ReconArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int W = a.width_mbs, H = a.height_mbs;
+    QTables &B = *reinterpret_cast<QTables *>(smem);
+    uint8_t *lines = smem + sizeof(QTables);              // [quarter][ luma W*16 | Cb W*8 | Cr W*8 ]
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane_c = threadIdx.x & 63;
+    uint8_t *wave_lds = lines + (size_t)4 * W * 32 + (size_t)wave * 4 * sizeof(QLds);
+
+    // ---- one-time table setup ----
+    for (int i = threadIdx.x; i < 52; i += NW * 64) {
+        const int m = i % 6, s = i / 6;
+        const int shl = max(s - 4, 0), shr = max(4 - s, 0), rnd = (1 << shr) >> 1;
+        int4 e;
+        e.x = (16 * c_v4x4[m * 3 + 0]) << shl;
+        e.y = (16 * c_v4x4[m * 3 + 1]) << shl;
+        e.z = (16 * c_v4x4[m * 3 + 2]) << shl;
+        e.w = shr | (rnd << 8) | (s << 16) | (m << 24);
+        B.q4[i] = e;
+        B.ls0[i] = 16 * c_v4x4[m * 3 + 0];
+    }
+    for (int i = threadIdx.x; i < 36; i += NW * 64) B.ls8[i] = 16 * c_v8x8[i];
+    for (int i = threadIdx.x; i < 64; i += NW * 64) B.qpc[i] = (uint8_t)((i < 30) ? i : c_qpc[min(i, 51) - 30]);
+    for (int i = threadIdx.x; i < 2 * 9 * 16; i += NW * 64)
+        B.tap4[i] = tap4_entry((i >> 4) % 9, i & 3, (i >> 2) & 3, i >= 9 * 16);
+    for (int i = threadIdx.x; i < 9 * 64; i += NW * 64) B.tap8[i] = tap8_entry(i >> 6, i & 7, (i >> 3) & 7);
+    if (threadIdx.x < 16) B.progress[threadIdx.x] = 0;
+    if (threadIdx.x == 16) B.abort_flag = 0;
+    __syncthreads();
+
+    const int pitch = W * 16, cpitch = W * 8;
+    const size_t plane_y = (size_t)W * H * 256, plane_c = (size_t)W * H * 64;
+    const int up_wave = (wave + NW - 1) % NW;
+
+    // this lane's picture
+    const int q_c = lane_c >> 4;
+    const int frame_raw = (int)blockIdx.x * 4 + q_c;
+    const bool valid = frame_raw < a.n_frames;            // a short last workgroup repeats the last picture, stores off
+    const int frame = min(frame_raw, a.n_frames - 1);
+    const uint8_t *fpacked = a.packed + (size_t)frame * W * H * MVHP_MB_BYTES;
+    uint8_t *fy = a.yuv + (size_t)frame * W * H * 384;
+    uint8_t *frgb = a.rgb ? a.rgb + (size_t)frame * W * H * 768 : nullptr;
+
+    // Packed records are prefetched one macroblock ahead into the registers of the lanes that consume them:
+    // every lane of the quarter reads the 32-byte header (same address: one fetch), lane j the 32 bytes of
+    // luma block j and, for j < 8, the 32 bytes of chroma block j.
+    int4 pH0, pH1, pLA, pLB, pCA, pCB;
+    auto prefetch = [&](int prow, int px, int lane_p) {
+        const int4 z = make_int4(0, 0, 0, 0);
+        pH0 = pH1 = pLA = pLB = pCA = pCB = z;
+        if (prow >= H) return;
+        const int jj = lane_p & 15;
+        const uint8_t *rec = fpacked + (size_t)(prow * W + px) * MVHP_MB_BYTES;
+        pH0 = *reinterpret_cast<const int4 *>(rec);
+        pH1 = *reinterpret_cast<const int4 *>(rec + 16);
+        pLA = *reinterpret_cast<const int4 *>(rec + MVHP_MB_HEADER_BYTES + jj * 32);
+        pLB = *reinterpret_cast<const int4 *>(rec + MVHP_MB_HEADER_BYTES + jj * 32 + 16);
+        if (jj < 8) {
+            pCA = *reinterpret_cast<const int4 *>(rec + MVHP_MB_HEADER_BYTES + (16 + jj) * 32);
+            pCB = *reinterpret_cast<const int4 *>(rec + MVHP_MB_HEADER_BYTES + (16 + jj) * 32 + 16);
+        }
+    };
+    prefetch(wave, 0, lane_c);
+
+    int done = 0; // macroblocks completed by this wave
+    for (int row = wave; row < H; row += NW) {
+        const int pass = row / NW;
+        const int up_base = ((wave == 0) ? (pass - 1) : pass) * W; // MBs the upper wave finished before its row (row-1)
+        const bool Bv = row > 0;
+#pragma unroll 1
+        for (int mbx = 0; mbx < W; mbx++) {
+            // Re-materialise the lane id every macroblock: it keeps the compiler from hoisting hundreds of
+            // lane-dependent LDS addresses out of this loop.
+            int lane = lane_c;
+            asm volatile("" : "+v"(lane));
+            const int q = lane >> 4, j = lane & 15;
+            QLds &Q = *reinterpret_cast<QLds *>(wave_lds + q * sizeof(QLds));
+            uint8_t *line_y = lines + (size_t)q * W * 32;
+            uint8_t *line_cb = line_y + W * 16;
+            uint8_t *line_cr = line_cb + W * 8;
+            const bool A = mbx > 0, C = Bv && (mbx < W - 1), D = A && Bv;
+
+            const int4 cH0 = pH0, cH1 = pH1, cLA = pLA, cLB = pLB, cCA = pCA, cCB = pCB;
+            {   // next macroblock of this wave: same row, or the first of its next row
+                int nrow = row, nx = mbx + 1;
+                if (nx >= W) { nrow = row + NW; nx = 0; }
+                prefetch(nrow, nx, lane);
+            }
+            const uint32_t h0 = (uint32_t)cH0.x, h1 = (uint32_t)cH0.y, nz = (uint32_t)cH0.z;
+            const uint32_t m0 = (uint32_t)cH0.w, m1 = (uint32_t)cH1.x, m2 = (uint32_t)cH1.y, m3 = (uint32_t)cH1.z;
+            const int kind = h0 & 255;
+            const int qpy = min((int)((h0 >> 8) & 255), 51);
+            const int cmode = (h0 >> 24) & 255, i16mode = h1 & 255;
+            // Intra16x16 at QP'Y == 36 yields a non-zero DC term even from all-zero levels
+            // (h264_transform.c:797-808), so the residual stage cannot be skipped there.
+            const bool quirk36 = (kind == MVHP_KIND_I16x16) && (qpy == 36);
+            const bool need_l = ((nz & 0xffffu) != 0) || quirk36;
+            const bool need_c = (nz & 0xff0000u) != 0;
+            const bool any_l = __builtin_amdgcn_ballot_w64(need_l) != 0;
+            const bool any_c = __builtin_amdgcn_ballot_w64(need_c) != 0;
+
+            // luma block geometry (luma4x4BlkIdx j)
+            const int xO = (((j >> 2) & 1) << 3) | ((j & 1) << 2);
+            const int yO = ((j >> 3) << 3) | (((j >> 1) & 1) << 2);
+
+            // =====================================================================================
+            // residuals (no neighbour dependency: done before waiting for the row above)
+            // =====================================================================================
+            int r2[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // luma block j: packed int16 pairs, row-major
+            int c2[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // chroma block j (j < 8)
+            if (any_l) {
+                const int4 qt = B.q4[qpy];
+                const int shr = qt.w & 255, rnd = (qt.w >> 8) & 255, s = (qt.w >> 16) & 255, m = (qt.w >> 24) & 255;
+                if (kind == MVHP_KIND_I8x8) {
+                    // ---- luma 8x8 (transform_8x8_residual, h264_transform.c:1205-1383): lane j holds rows
+                    //      (2i, 2i+1), i = j & 3, of 8x8 block j >> 2; rows in registers, columns after an LDS
+                    //      transpose, two blocks at a time ----
+                    const int r0 = (j & 3) * 2;
+                    const int *l8 = &B.ls8[m * 6];
+                    const int4 l8a = make_int4(l8[0], l8[1], l8[2], l8[3]);
+                    const int2 l8b = make_int2(l8[4], l8[5]);
+                    // classes (h264.c:438-446) of the even row: r0%4==0 -> (0,3,4) else (4,5,2); odd row: (3,1,5)
+                    const bool r4 = (r0 & 2) == 0;
+                    const int e0 = r4 ? l8a.x : l8b.x, e1 = r4 ? l8a.w : l8b.y, e2 = r4 ? l8b.x : l8a.z;
+                    const int o0 = l8a.w, o1 = l8a.y, o2 = l8b.y;
+                    int d0[8], d1[8];
+                    unpack8(cLA, d0);
+                    unpack8(cLB, d1);
+                    if (qpy > 35) {
+                        const int sh = (s - 6) & 31;
+#pragma unroll
+                        for (int c = 0; c < 8; c++) {
+                            const int le = (c & 1) ? e1 : ((c & 3) == 0 ? e0 : e2), lo = (c & 1) ? o1 : ((c & 3) == 0 ? o0 : o2);
+                            d0[c] = (int)((unsigned)(d0[c] * le) << sh);
+                            d1[c] = (int)((unsigned)(d1[c] * lo) << sh);
+                        }
+                    } else {
+                        const int rn = 1 << ((5 - s) & 31), sh = (6 - s) & 31;
+#pragma unroll
+                        for (int c = 0; c < 8; c++) {
+                            const int le = (c & 1) ? e1 : ((c & 3) == 0 ? e0 : e2), lo = (c & 1) ? o1 : ((c & 3) == 0 ? o0 : o2);
+                            d0[c] = (d0[c] * le + rn) >> sh;
+                            d1[c] = (d1[c] * lo + rn) >> sh;
+                        }
+                    }
+                    if (r0 == 0) d0[0] += 32; // rounding term of the final (m + 32) >> 6, see idct4x4
+                    idct8_1d(d0);
+                    idct8_1d(d1);
+                    int col[2][8];
+#pragma unroll
+                    for (int h = 0; h < 2; h++) {
+                        if ((j >> 3) == h) {
+                            int32_t *dst = &Q.scr[((j >> 2) & 1) * 64 + r0 * 8];
+                            *reinterpret_cast<int4 *>(dst) = make_int4(d0[0], d0[1], d0[2], d0[3]);
+                            *reinterpret_cast<int4 *>(dst + 4) = make_int4(d0[4], d0[5], d0[6], d0[7]);
+                            *reinterpret_cast<int4 *>(dst + 8) = make_int4(d1[0], d1[1], d1[2], d1[3]);
+                            *reinterpret_cast<int4 *>(dst + 12) = make_int4(d1[4], d1[5], d1[6], d1[7]);
+                        }
+                        WAVE_SYNC();
+#pragma unroll
+                        for (int i = 0; i < 8; i++) col[h][i] = Q.scr[(j >> 3) * 64 + i * 8 + (j & 7)];
+                        idct8_1d(col[h]);
+                        WAVE_SYNC();
+                    }
+                    // res[blk8][column][row]: lane j column j & 7 of block 2h + (j >> 3)
+#pragma unroll
+                    for (int h = 0; h < 2; h++) {
+                        int4 o;
+                        o.x = pack_res(col[h][0] >> 6, col[h][1] >> 6);
+                        o.y = pack_res(col[h][2] >> 6, col[h][3] >> 6);
+                        o.z = pack_res(col[h][4] >> 6, col[h][5] >> 6);
+                        o.w = pack_res(col[h][6] >> 6, col[h][7] >> 6);
+                        *reinterpret_cast<int4 *>(&Q.res[(2 * h + (j >> 3)) * 64 + (j & 7) * 8]) = o;
+                    }
+                } else {
+                    // ---- luma 4x4 (transform_4x4_residual, h264_transform.c:1049-1191) ----
+                    int d[16];
+                    unpack8(cLA, d);
+                    unpack8(cLB, d + 8);
+                    int dc = 0;
+                    if (kind == MVHP_KIND_I16x16) {
+                        // transform_16x16_lumadc, h264_transform.c:756-812 (incl. the `qP > 36` test): the 16 DC
+                        // levels sit one per lane; rows/columns of the 4x4 DC matrix are lane bits (3,1) / (2,0)
+                        const int base = (lane & 48);
+                        const int cj = ((j >> 1) & 2) | (j & 1), ci = ((j >> 2) & 2) | ((j >> 1) & 1);
+                        const int aP = (base | (j & ~5) | ((j >> 2) & 1)) << 2;
+                        const int g = had4_lanes(d[0], dpp_quad<DPP_XOR1>(d[0]), cj, aP, aP | (4 << 2));
+                        const int bP = (base | (j & ~10) | ((j >> 2) & 2)) << 2;
+                        const int f = had4_lanes(g, dpp_quad<DPP_XOR2>(g), ci, bP, bP | (8 << 2));
+                        const int lsA = B.ls0[qpy];
+                        if (qpy > 36) dc = (int)((unsigned)(f * lsA) << ((s - 6) & 31));
+                        else dc = (int)((unsigned)(f * lsA) + (1u << ((5 - s) & 31))) >> ((6 - s) & 31);
+                    }
+                    // quant4x4, h264_transform.c:1100-1134: ((c*LS + rnd) >> shr) << shl, the left shift folded into LS
+#pragma unroll
+                    for (int i = 0; i < 16; i++) {
+                        const int r = i >> 2, c = i & 3;
+                        const int ls = ((r & 1) == 0 && (c & 1) == 0) ? qt.x : (((r & 1) && (c & 1)) ? qt.y : qt.z);
+                        d[i] = (__mul24(d[i], ls) + rnd) >> shr;
+                    }
+                    if (kind == MVHP_KIND_I16x16) d[0] = dc;
+                    d[0] += 32;
+                    idct4x4(d);
+#pragma unroll
+                    for (int i = 0; i < 8; i++) r2[i] = pack_res(d[2 * i], d[2 * i + 1]);
+                    if (!need_l) {
+#pragma unroll
+                        for (int i = 0; i < 8; i++) r2[i] = 0;
+                    }
+                    if (kind == MVHP_KIND_I4x4) {
+                        *reinterpret_cast<int4 *>(&Q.res[j * 16]) = make_int4(r2[0], r2[1], r2[2], r2[3]);
+                        *reinterpret_cast<int4 *>(&Q.res[j * 16 + 8]) = make_int4(r2[4], r2[5], r2[6], r2[7]);
+                    }
+                }
+            }
+            if (any_c) {
+                // ---- chroma 4x4 + transform_2x2_chromadc (h264_transform.c:827-860, :924-936, :988-1005) ----
+                const int pl = (j >> 2) & 1, k = j & 3;
+                const int qpi = min(max(qpy + (pl ? a.cqp_off_cr : a.cqp_off_cb), 0), 51);
+                const int qpc = B.qpc[qpi];
+                const int4 qt = B.q4[qpc];
+                const int shr = qt.w & 255, rnd = (qt.w >> 8) & 255, s = (qt.w >> 16) & 255;
+                int d[16];
+                unpack8(cCA, d);
+                unpack8(cCB, d + 8);
+                const int c0 = dpp_quad<0x00>(d[0]), c1 = dpp_quad<0x55>(d[0]), c2v = dpp_quad<0xAA>(d[0]), c3 = dpp_quad<0xFF>(d[0]);
+                const int f = (k == 0) ? (c0 + c1 + c2v + c3) : (k == 1) ? (c0 - c1 + c2v - c3)
+                            : (k == 2) ? (c0 + c1 - c2v - c3) : (c0 - c1 - c2v + c3);
+                const int dc = (int)((unsigned)(f * B.ls0[qpc]) << s) >> 5;
+#pragma unroll
+                for (int i = 0; i < 16; i++) {
+                    const int r = i >> 2, c = i & 3;
+                    const int ls = ((r & 1) == 0 && (c & 1) == 0) ? qt.x : (((r & 1) && (c & 1)) ? qt.y : qt.z);
+                    d[i] = (__mul24(d[i], ls) + rnd) >> shr;
+                }
+                d[0] = dc + 32;
+                idct4x4(d);
+#pragma unroll
+                for (int i = 0; i < 8; i++) c2[i] = need_c ? pack_res(d[2 * i], d[2 * i + 1]) : 0;
+            }
+
+            // =====================================================================================
+            // wait for the row above: needs columns <= min(mbx+1, W-1); then fetch the top neighbours
+            // =====================================================================================
+            if (Bv) {
+                const int need = up_base + min(mbx + 2, W);
+                int spins = 0;
+                while (__hip_atomic_load(&B.progress[up_wave], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < need) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > (1 << 22) || __hip_atomic_load(&B.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
+                        if (lane == 0) { __hip_atomic_store(&B.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); atomicOr(a.err, 1u); }
+                        return;
+                    }
+                }
+                asm volatile("" ::: "memory");
+                // lanes 0-3 luma top, 4-5 luma up-right (when C), 6-7 Cb top, 8-9 Cr top: one dword each
+                if (j < 10 && (C || (j >> 1) != 2)) {
+                    uint8_t *dst;
+                    const uint8_t *src;
+                    if (j < 4) { dst = &Q.T[16 + j * 4]; src = &line_y[mbx * 16 + j * 4]; }
+                    else if (j < 6) { dst = &Q.T[32 + (j - 4) * 4]; src = &line_y[mbx * 16 + 16 + (j - 4) * 4]; }
+                    else if (j < 8) { dst = &Q.TC[0][8 + (j - 6) * 4]; src = &line_cb[mbx * 8 + (j - 6) * 4]; }
+                    else { dst = &Q.TC[1][8 + (j - 8) * 4]; src = &line_cr[mbx * 8 + (j - 8) * 4]; }
+                    *reinterpret_cast<uint32_t *>(dst) = *reinterpret_cast<const uint32_t *>(src);
+                }
+            }
+            WAVE_SYNC();
+
+            // =====================================================================================
+            // luma prediction
+            // =====================================================================================
+            if (kind == MVHP_KIND_I16x16) {
+                // h264_intra_prediction.c:1809-2141 + transform16x16_luma; lane j predicts its own 4x4 block
+                uint32_t pw[4] = {0u, 0u, 0u, 0u};
+                if (i16mode == 0) {
+                    if (Bv) { const uint32_t t = *reinterpret_cast<const uint32_t *>(&Q.T[16 + xO]); pw[0] = pw[1] = pw[2] = pw[3] = t; }
+                } else if (i16mode == 1) {
+                    if (A) {
+                        const uint32_t l = *reinterpret_cast<const uint32_t *>(&Q.Lcol[yO]);
+#pragma unroll
+                        for (int y = 0; y < 4; y++) pw[y] = ((l >> (8 * y)) & 255u) * 0x01010101u;
+                    }
+                } else if (i16mode == 2) {
+                    const uint4 topv = *reinterpret_cast<const uint4 *>(&Q.T[16]);
+                    const uint4 lefv = *reinterpret_cast<const uint4 *>(Q.Lcol);
+                    const int sumH = sum4(topv.x) + sum4(topv.y) + sum4(topv.z) + sum4(topv.w);
+                    const int sumV = sum4(lefv.x) + sum4(lefv.y) + sum4(lefv.z) + sum4(lefv.w);
+                    int v;
+                    if (A && Bv) v = (sumH + sumV + 16) >> 5;
+                    else if (A) v = (sumV + 8) >> 4;
+                    else if (Bv) v = (sumH + 8) >> 4;
+                    else v = 128;
+                    pw[0] = pw[1] = pw[2] = pw[3] = (uint32_t)v * 0x01010101u;
+                } else if (i16mode == 3) {
+                    if (A && Bv) {
+                        const uint4 topv = *reinterpret_cast<const uint4 *>(&Q.T[16]);
+                        const uint4 lefv = *reinterpret_cast<const uint4 *>(Q.Lcol);
+                        const int cor = Q.T[15];
+                        const uint32_t tw[4] = {topv.x, topv.y, topv.z, topv.w};
+                        const uint32_t lw[4] = {lefv.x, lefv.y, lefv.z, lefv.w};
+                        int Hh = 0, Vv = 0;
+#pragma unroll
+                        for (int i = 0; i < 8; i++) {
+                            const int hi = 8 + i, lo = 6 - i;
+                            const int th = (tw[hi >> 2] >> ((hi & 3) * 8)) & 255;
+                            const int lh = (lw[hi >> 2] >> ((hi & 3) * 8)) & 255;
+                            const int tl = (lo < 0) ? cor : (int)((tw[lo >> 2] >> ((lo & 3) * 8)) & 255);
+                            const int ll = (lo < 0) ? cor : (int)((lw[lo >> 2] >> ((lo & 3) * 8)) & 255);
+                            Hh += (i + 1) * (th - tl);
+                            Vv += (i + 1) * (lh - ll);
+                        }
+                        const int aa = 16 * ((int)(lefv.w >> 24) + (int)(topv.w >> 24));
+                        const int bb = (5 * Hh + 32) >> 6;
+                        const int cc = (5 * Vv + 32) >> 6;
+                        const int v00 = aa + bb * (xO - 7) + cc * (yO - 7) + 16;
+#pragma unroll
+                        for (int y = 0; y < 4; y++) pw[y] = plane_row(v00 + cc * y, bb);
+                    }
+                }
+                emit_block(&Q.T[(yO + 1) * 32 + 16 + xO], 32, pw, r2);
+            } else if (kind == MVHP_KIND_I4x4) {
+                // Intra 4x4: 16 dependent block steps, lane j = one sample of the block.
+                // h264_intra_prediction.c:161-177, :315-483, :496-960 + transform4x4_luma (h264_transform.c:121-156).
+                // availability per luma4x4BlkIdx (wave-uniform): deriv_neighbouringlocations, h264_spatial.c:739-786
+                constexpr uint32_t X0 = (1u << 0) | (1u << 2) | (1u << 8) | (1u << 10);   // blocks with xO == 0
+                constexpr uint32_t Y0 = (1u << 0) | (1u << 1) | (1u << 4) | (1u << 5);    // blocks with yO == 0
+                const uint32_t av_left = A ? 0xffffu : (0xffffu & ~X0);
+                const uint32_t av_up = Bv ? 0xffffu : (0xffffu & ~Y0);
+                const uint32_t av_upleft = (0xffffu & ~(X0 | Y0)) | (Bv ? ((1u << 1) | (1u << 4) | (1u << 5)) : 0u) |
+                                           (A ? ((1u << 2) | (1u << 8) | (1u << 10)) : 0u) | (D ? 1u : 0u);
+                const uint32_t av_upright = ((1u << 2) | (1u << 6) | (1u << 8) | (1u << 9) | (1u << 10) | (1u << 12) | (1u << 14)) |
+                                            (Bv ? ((1u << 0) | (1u << 1) | (1u << 4)) : 0u) | (C ? (1u << 5) : 0u);
+                // neighbours each mode needs, 3 bits per mode: bit0 left, bit1 up, bit2 up-left (mode 2 = DC apart)
+                constexpr uint32_t REQ = (2u << 0) | (1u << 3) | (0u << 6) | (2u << 9) | (7u << 12) | (7u << 15) | (7u << 18) |
+                                         (2u << 21) | (1u << 24);
+                // control word of block j, computed by lane j and broadcast inside the quarter at step j:
+                // bits 0-1 left/up available, bit 2 mode is DC, bit 3 prediction allowed, bits 8.. tap table row offset
+                uint32_t info;
+                {
+                    const uint32_t mw = (j < 4) ? m0 : (j < 8) ? m1 : (j < 12) ? m2 : m3;
+                    const uint32_t mode = (mw >> ((j & 3) * 8)) & 255u;
+                    const uint32_t avail = ((av_left >> j) & 1u) | (((av_up >> j) & 1u) << 1) | (((av_upleft >> j) & 1u) << 2);
+                    const uint32_t req = (REQ >> (min(mode, 8u) * 3)) & 7u;
+                    const uint32_t ok = (((req & ~avail) == 0u) && (mode < 9u)) ? 1u : 0u; // else the prediction stays 0 (:442)
+                    const uint32_t trow = (((av_upright >> j) & 1u) ? 0u : 9u) + min(mode, 8u);
+                    info = (avail & 3u) | ((mode == 2u) ? 4u : 0u) | (ok << 3) | ((trow * 64u) << 8);
+                }
+                const int pix = (j >> 2) * 32 + (j & 3);   // this lane's sample inside a block, tile units
+                const uint8_t *T = Q.T;
+                const uint8_t *tapb = reinterpret_cast<const uint8_t *>(B.tap4) + j * 4;
+                const bool has_res = need_l;
+                // software pipeline: control word, table entry and residual of block b+1 are fetched before block
+                // b's dependent tile reads
+                const int qbase4 = (lane & 48) << 2;
+                uint32_t inf = quarter_bcast(info, qbase4, 0);
+                uint32_t e_nx = *reinterpret_cast<const uint32_t *>(tapb + (inf >> 8));
+                int r_nx = has_res ? (int)Q.res[j] : 0;
+#pragma unroll
+                for (int blk = 0; blk < 16; blk++) {
+                    const int bxO = (((blk >> 2) & 1) << 3) | ((blk & 1) << 2);
+                    const int byO = ((blk >> 3) << 3) | (((blk >> 1) & 1) << 2);
+                    const int base = (byO + 1) * 32 + 16 + bxO;     // tile index of the block's top-left sample
+                    const uint32_t cur = inf;
+                    const uint32_t e = e_nx;
+                    const int r = r_nx;
+                    if (blk < 15) {
+                        inf = quarter_bcast(info, qbase4, blk + 1);
+                        e_nx = *reinterpret_cast<const uint32_t *>(tapb + (inf >> 8));
+                        r_nx = has_res ? (int)Q.res[(blk + 1) * 16 + j] : 0;
+                    }
+                    const int okmask = (cur & 8u) ? -1 : 0;
+                    const int ta = T[base - 33 + (int)(e & 255)];
+                    const int tb = T[base - 33 + (int)((e >> 8) & 255)];
+                    const int tc = T[base - 33 + (int)(e >> 16)];
+                    int pred = ((ta + 2 * tb + tc + 2) >> 2) & okmask;
+                    if (__builtin_amdgcn_ballot_w64((cur & 4u) != 0) != 0) { // some quarter predicts DC
+                        const int sumH = sum4(*reinterpret_cast<const uint32_t *>(&T[base - 32]));
+                        const int sumV = T[base - 1] + T[base + 31] + T[base + 63] + T[base + 95];
+                        const uint32_t lu = cur & 3u; // 3 both, 1 left only, 2 up only, 0 none
+                        const int both = (sumH + sumV + 4) >> 3, l = (sumV + 2) >> 2, u = (sumH + 2) >> 2;
+                        const int dcv = (lu == 3u) ? both : (lu == 1u) ? l : (lu == 2u) ? u : 128;
+                        if (cur & 4u) pred = dcv;
+                    }
+                    Q.T[base + pix] = (uint8_t)clip255(pred + r);
+                    WAVE_SYNC();
+                }
+            } else {
+                // Intra 8x8: h264_intra_prediction.c:1107-1353 (edge filter) + :1366-1793 + transform8x8_luma;
+                // lane j predicts samples (4*(j&1) .. +3, j>>1) of the block
+#pragma unroll 1
+                for (int blk = 0; blk < 4; blk++) {
+                    const int bxO = (blk & 1) * 8, byO = (blk >> 1) * 8;
+                    const int mode = (int)((m0 >> (blk * 8)) & 255u);
+                    const bool left = (bxO > 0) || A;
+                    const bool up = (byO > 0) || Bv;
+                    const bool upleft = (bxO > 0) ? ((byO > 0) || Bv) : ((byO > 0) ? A : D);
+                    const bool upright = (blk == 0) ? Bv : (blk == 1) ? C : (blk == 2);
+                    const uint8_t *Trow = &Q.T[byO * 32 + 16 + bxO];
+                    const uint8_t *Tcol = &Q.T[(byO + 1) * 32 + 15 + bxO];
+#pragma unroll
+                    for (int half = 0; half < 2; half++) {
+                        const int el = j + 16 * half;
+                        if (el < 28) {
+                            // raw edge sample for EE8 index e: e<=9: left[9-e] (clamped), 10: corner, >=11: top[e-11]
+                            const int e = min(max(el, 2), 26);
+                            const int maxi = upright ? 15 : 7;
+                            int lo = e - 1, hi = e + 1;
+                            if (e == 2 || (e == 11 && !upleft) || (e == 10 && !left)) lo = e;
+                            if (e == 26 || (e == 9 && !upleft) || (e == 10 && !up)) hi = e;
+                            int v[3];
+                            const int idxs[3] = {lo, e, hi};
+#pragma unroll
+                            for (int t = 0; t < 3; t++) {
+                                const int idx = idxs[t];
+                                v[t] = (idx >= 10) ? (int)Trow[min(idx - 11, maxi)] : (int)Tcol[(9 - idx) * 32];
+                            }
+                            Q.E8[el] = (uint8_t)((v[0] + 2 * v[1] + v[2] + 2) >> 2);
+                        }
+                    }
+                    WAVE_SYNC();
+                    {
+                        const int y = j >> 1, x0 = (j & 1) * 4;
+                        uint32_t pwv = 0;
+                        if (mode == 2) {
+                            const uint32_t *E = reinterpret_cast<const uint32_t *>(Q.E8);
+                            const uint32_t w0 = E[0], w1 = E[1], w2 = E[2], w3 = E[3], w4 = E[4];
+                            const int sumV = sum4(w0 & 0xffff0000u) + sum4(w1) + sum4(w2 & 0x0000ffffu);       // E8[2..9]
+                            const int sumH = sum4(w2 & 0xff000000u) + sum4(w3) + sum4(w4 & 0x00ffffffu);       // E8[11..18]
+                            int v;
+                            if (left && up) v = (sumH + sumV + 8) >> 4;
+                            else if (left) v = (sumV + 4) >> 3;
+                            else if (up) v = (sumH + 4) >> 3;
+                            else v = 128;
+                            pwv = (uint32_t)v * 0x01010101u;
+                        } else {
+                            bool ok;
+                            switch (mode) {
+                            case 0: case 3: case 7: ok = up; break;
+                            case 1: case 8: ok = left; break;
+                            default: ok = left && up && upleft; break;
+                            }
+                            if (ok && mode < 9) {
+                                const uint4 e4 = *reinterpret_cast<const uint4 *>(&B.tap8[mode * 64 + y * 8 + x0]);
+                                const uint32_t ee[4] = {e4.x, e4.y, e4.z, e4.w};
+#pragma unroll
+                                for (int x = 0; x < 4; x++) {
+                                    const int v0 = Q.E8[ee[x] & 255], v1 = Q.E8[(ee[x] >> 8) & 255], v2 = Q.E8[ee[x] >> 16];
+                                    pwv |= (uint32_t)((v0 + 2 * v1 + v2 + 2) >> 2) << (8 * x);
+                                }
+                            }
+                        }
+                        int rr[4] = {0, 0, 0, 0};
+                        if (need_l) {
+#pragma unroll
+                            for (int x = 0; x < 4; x++) rr[x] = (int)Q.res[blk * 64 + (x0 + x) * 8 + y];
+                        }
+                        uint32_t out = 0;
+#pragma unroll
+                        for (int x = 0; x < 4; x++) out |= (uint32_t)clip255((int)((pwv >> (8 * x)) & 255u) + rr[x]) << (8 * x);
+                        *reinterpret_cast<uint32_t *>(&Q.T[(byO + y + 1) * 32 + 16 + bxO + x0]) = out;
+                    }
+                    WAVE_SYNC();
+                }
+            }
+
+            // =====================================================================================
+            // chroma prediction (h264_intra_prediction.c:2157-2564 + transform4x4_chroma): lane j < 8 predicts
+            // its own 4x4 block (plane j >> 2, block j & 3)
+            // =====================================================================================
+            if (j < 8) {
+                const int pl = j >> 2, k = j & 3;
+                const int cx = (k & 1) * 4, cy = (k >> 1) * 4;
+                uint8_t *TCp = Q.TC[pl];
+                uint32_t pw[4] = {0u, 0u, 0u, 0u};
+                const uint32_t topw = *reinterpret_cast<const uint32_t *>(&TCp[8 + cx]);
+                const uint32_t lefw = *reinterpret_cast<const uint32_t *>(&Q.LcolC[pl][cy]);
+                if (cmode == 0) {
+                    const int bx = k & 1, by = k >> 1;
+                    const int sH = sum4(topw), sV = sum4(lefw);
+                    int v;
+                    if (!A && !Bv) v = 128;
+                    else if (bx == by) {
+                        if (A && Bv) v = (sH + sV + 4) >> 3;
+                        else if (A) v = (sV + 2) >> 2;
+                        else v = (sH + 2) >> 2;
+                    } else if (bx == 1) { // xO > 0, yO == 0: prefers top
+                        v = Bv ? ((sH + 2) >> 2) : ((sV + 2) >> 2);
+                    } else {              // xO == 0, yO > 0: prefers left
+                        v = A ? ((sV + 2) >> 2) : ((sH + 2) >> 2);
+                    }
+                    pw[0] = pw[1] = pw[2] = pw[3] = (uint32_t)v * 0x01010101u;
+                } else if (cmode == 1) {
+                    if (A) {
+#pragma unroll
+                        for (int y = 0; y < 4; y++) pw[y] = ((lefw >> (8 * y)) & 255u) * 0x01010101u;
+                    }
+                } else if (cmode == 2) {
+                    if (Bv) pw[0] = pw[1] = pw[2] = pw[3] = topw;
+                } else if (cmode == 3) {
+                    if (A && Bv) {
+                        const uint2 topv = *reinterpret_cast<const uint2 *>(&TCp[8]);
+                        const uint2 lefv = *reinterpret_cast<const uint2 *>(Q.LcolC[pl]);
+                        const int cor = TCp[7];
+                        const uint32_t tw[2] = {topv.x, topv.y}, lw[2] = {lefv.x, lefv.y};
+                        int Hh = 0, Vv = 0;
+#pragma unroll
+                        for (int i = 0; i < 4; i++) {
+                            const int hi = 4 + i, lo = 2 - i;
+                            const int th = (tw[hi >> 2] >> ((hi & 3) * 8)) & 255;
+                            const int lh = (lw[hi >> 2] >> ((hi & 3) * 8)) & 255;
+                            const int tl = (lo < 0) ? cor : (int)((tw[0] >> (lo * 8)) & 255);
+                            const int ll = (lo < 0) ? cor : (int)((lw[0] >> (lo * 8)) & 255);
+                            Hh += (i + 1) * (th - tl);
+                            Vv += (i + 1) * (lh - ll);
+                        }
+                        const int aa = 16 * ((int)(lefv.y >> 24) + (int)(topv.y >> 24));
+                        const int bb = (34 * Hh + 32) >> 6;
+                        const int cc = (34 * Vv + 32) >> 6;
+                        const int v00 = aa + bb * (cx - 3) + cc * (cy - 3) + 16;
+#pragma unroll
+                        for (int y = 0; y < 4; y++) pw[y] = plane_row(v00 + cc * y, bb);
+                    }
+                }
+                emit_block(&TCp[(cy + 1) * 16 + 8 + cx], 16, pw, c2);
+            }
+            WAVE_SYNC();
+
+            // =====================================================================================
+            // write-out: lane j stores luma row j (16 B), chroma row j & 7 of plane j >> 3 (8 B) and, fused,
+            // the 16 RGB samples of row j (48 B) -- mb_to_rgb, export_utils.c:209-324
+            // =====================================================================================
+            {
+                const uint4 yv = *reinterpret_cast<const uint4 *>(&Q.T[(j + 1) * 32 + 16]);
+                const uint2 cv = *reinterpret_cast<const uint2 *>(&Q.TC[j >> 3][((j & 7) + 1) * 16 + 8]);
+                if (valid) {
+                    *reinterpret_cast<uint4 *>(&fy[(size_t)(row * 16 + j) * pitch + mbx * 16]) = yv;
+                    *reinterpret_cast<uint2 *>(fy + plane_y + (size_t)(j >> 3) * plane_c + (size_t)(row * 8 + (j & 7)) * cpitch + mbx * 8) = cv;
+                }
+                if (frgb) {
+                    const uint2 cbv = *reinterpret_cast<const uint2 *>(&Q.TC[0][((j >> 1) + 1) * 16 + 8]);
+                    const uint2 crv = *reinterpret_cast<const uint2 *>(&Q.TC[1][((j >> 1) + 1) * 16 + 8]);
+                    const uint32_t yw[4] = {yv.x, yv.y, yv.z, yv.w};
+                    const uint32_t cbw[2] = {cbv.x, cbv.y}, crw[2] = {crv.x, crv.y};
+                    uint32_t o[12];
+#pragma unroll
+                    for (int g = 0; g < 4; g++) {       // four samples -> three dwords
+                        uint32_t ch[12];
+#pragma unroll
+                        for (int t = 0; t < 4; t++) {
+                            const int x = g * 4 + t;
+                            const int l = (yw[g] >> (t * 8)) & 255;
+                            const int cb = (cbw[x >> 3] >> (((x >> 1) & 3) * 8)) & 255, cr = (crw[x >> 3] >> (((x >> 1) & 3) * 8)) & 255;
+                            const int ly = (298 * l) >> 8;
+                            ch[t * 3 + 0] = (uint32_t)clip255(ly + ((408 * cr) >> 8) - 222);
+                            ch[t * 3 + 1] = (uint32_t)clip255(ly - ((100 * cb) >> 8) - ((208 * cr) >> 8) + 135);
+                            ch[t * 3 + 2] = (uint32_t)clip255(ly + ((516 * cb) >> 8) - 276);
+                        }
+                        o[g * 3 + 0] = ch[0] | (ch[1] << 8) | (ch[2] << 16) | (ch[3] << 24);
+                        o[g * 3 + 1] = ch[4] | (ch[5] << 8) | (ch[6] << 16) | (ch[7] << 24);
+                        o[g * 3 + 2] = ch[8] | (ch[9] << 8) | (ch[10] << 16) | (ch[11] << 24);
+                    }
+                    if (valid) {
+                        uint4 *dst = reinterpret_cast<uint4 *>(frgb + ((size_t)(row * 16 + j) * pitch + mbx * 16) * 3);
+                        dst[0] = make_uint4(o[0], o[1], o[2], o[3]);
+                        dst[1] = make_uint4(o[4], o[5], o[6], o[7]);
+                        dst[2] = make_uint4(o[8], o[9], o[10], o[11]);
+                    }
+                }
+            }
+
+            // =====================================================================================
+            // neighbour state for the next macroblock / next row, then publish
+            // =====================================================================================
+            {
+                // corners (old top-right sample) by lanes 0-2, left columns: lane j luma row j; lane j chroma
+                // row j & 7 of plane j >> 3; bottom rows -> line buffer by lanes 0-7 (one dword each)
+                const uint8_t kl = Q.T[(j + 1) * 32 + 31];
+                const uint8_t kc = Q.TC[j >> 3][((j & 7) + 1) * 16 + 15];
+                uint8_t kk = 0;
+                uint8_t *kdst = &Q.T[15];
+                if (j == 0) kk = Q.T[31];
+                else if (j == 1) { kk = Q.TC[0][15]; kdst = &Q.TC[0][7]; }
+                else if (j == 2) { kk = Q.TC[1][15]; kdst = &Q.TC[1][7]; }
+                uint32_t bot = 0;
+                uint8_t *bdst = line_y;
+                if (j < 4) { bot = *reinterpret_cast<const uint32_t *>(&Q.T[16 * 32 + 16 + j * 4]); bdst = &line_y[mbx * 16 + j * 4]; }
+                else if (j < 6) { bot = *reinterpret_cast<const uint32_t *>(&Q.TC[0][8 * 16 + 8 + (j - 4) * 4]); bdst = &line_cb[mbx * 8 + (j - 4) * 4]; }
+                else if (j < 8) { bot = *reinterpret_cast<const uint32_t *>(&Q.TC[1][8 * 16 + 8 + (j - 6) * 4]); bdst = &line_cr[mbx * 8 + (j - 6) * 4]; }
+                WAVE_SYNC();
+                Q.T[(j + 1) * 32 + 15] = kl;
+                Q.Lcol[j] = kl;
+                Q.TC[j >> 3][((j & 7) + 1) * 16 + 7] = kc;
+                Q.LcolC[j >> 3][j & 7] = kc;
+                if (j < 3) *kdst = kk;
+                if (j < 8) *reinterpret_cast<uint32_t *>(bdst) = bot;
+            }
+            done++;
+            // LDS operations of one wave complete in order; the explicit wait makes the line-buffer
+            // writes land before the counter without waiting for the global plane stores (vmcnt).
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (lane == 0) __hip_atomic_store(&B.progress[wave], done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            WAVE_SYNC();
+        }
+    }
+}
+
+size_t recon_quad_lds_bytes(int width_mbs, int nw)
+{
+    return sizeof(QTables) + (size_t)4 * width_mbs * 32 + (size_t)nw * 4 * sizeof(QLds);
+}
+
+hipError_t launch_recon_quad(const ReconArgs &a, int nw, hipStream_t stream)
+{
+    const size_t lds = recon_quad_lds_bytes(a.width_mbs, nw);
+    const int groups = (a.n_frames + 3) / 4;
+    hipError_t e = hipSuccess;
+    switch (nw) {
+    case 4:
+        e = hipFuncSetAttribute((const void *)recon_quad_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(recon_quad_kernel<4>, dim3(groups), dim3(4 * 64), lds, stream, a);
+        break;
+    case 8:
+        e = hipFuncSetAttribute((const void *)recon_quad_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(recon_quad_kernel<8>, dim3(groups), dim3(8 * 64), lds, stream, a);
+        break;
+    case 16:
+        e = hipFuncSetAttribute((const void *)recon_quad_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(recon_quad_kernel<16>, dim3(groups), dim3(16 * 64), lds, stream, a);
+        break;
+    default:
+        return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+} // namespace mvhp

@@ -72,6 +72,8 @@ def lib():
     L.mvhp_destroy.argtypes = [vp]
     L.mvhp_set_waves_per_picture.restype = i32
     L.mvhp_set_waves_per_picture.argtypes = [vp, i32]
+    L.mvhp_set_layout.restype = i32
+    L.mvhp_set_layout.argtypes = [vp, i32]
     L.mvhp_set_fused_color.restype = i32
     L.mvhp_set_fused_color.argtypes = [vp, i32]
     L.mvhp_recon_batch_dev.restype = i32
@@ -129,6 +131,12 @@ class HotPath:
     def set_waves_per_picture(self, waves):
         if self._L.mvhp_set_waves_per_picture(self._h, int(waves)) != SUCCESS:
             raise MiniVideoError("waves per picture must be 0 (auto), 4, 8 or 16")
+
+    def set_layout(self, layout):
+        """0 auto, 1 one picture per workgroup (rows), 2 four pictures per workgroup (quad); speed only."""
+        code = {"auto": 0, "rows": 1, "quad": 2}.get(layout, layout)
+        if self._L.mvhp_set_layout(self._h, int(code)) != SUCCESS:
+            raise ValueError("layout must be auto/rows/quad")
 
     def set_fused_color(self, on):
         self._L.mvhp_set_fused_color(self._h, 1 if on else 0)

@@ -12,10 +12,12 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
-@pytest.fixture(scope="session")
-def hot():
-    """GPU reconstruction context through the C-ABI (fails loudly without libminivideo.so / a GPU)."""
+@pytest.fixture(scope="session", params=["rows", "quad"])
+def hot(request):
+    """GPU reconstruction context through the C-ABI (fails loudly without libminivideo.so / a GPU), once per
+    kernel layout: one picture per workgroup ("rows") and four pictures per workgroup ("quad")."""
     from minivideo_amd import HotPath
     h = HotPath(0)
+    h.set_layout(request.param)
     yield h
     h.close()
