@@ -184,8 +184,9 @@ static int pick_waves(const mvhp_ctx *c, const mvhp_stream_params_t *p, int n_fr
 {
     int nw = c->waves;
     if (quad) {
-        // speed only: 8-wave workgroups fit two to a CU (LDS); small batches take the wider workgroup
-        if (nw == 0) nw = (n_frames >= 8 * c->n_cus) ? 8 : 16;
+        // speed only: 8-wave workgroups fit one to a CU (LDS), 4-wave workgroups two
+        // (the quad kernel is built for 4 and 8 waves: at 16 its register budget would force spills)
+        if (nw == 0 || nw > 8) nw = 8;
         while (nw > 4 && (nw / 2) >= (int)p->height_mbs) nw /= 2;
         while (nw > 4 && mvhp::recon_quad_lds_bytes((int)p->width_mbs, nw) > c->max_lds) nw /= 2;
         return nw;

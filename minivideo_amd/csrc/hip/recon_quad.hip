@@ -40,9 +40,11 @@ struct __attribute__((aligned(16))) QLds {
     uint8_t Lcol[16];        // compact left neighbour column (luma)
     uint8_t LcolC[2][8];     // compact left neighbour columns (Cb, Cr)
     uint8_t E8[32];          // filtered Intra8x8 edge, see recon_device.h mode_entry()
-    uint8_t pad[16];         // 1440 B: quarters land 360 dwords apart (different banks)
+    uint8_t SY[16 * 64];     // output strip: four macroblocks of reconstructed luma, flushed as 64-byte row segments
+    uint8_t SC[2][8 * 32];   // output strip: four macroblocks of Cb / Cr (32-byte row segments)
+    uint8_t pad[16];         // 2976 B: quarters land 744 dwords apart (different banks)
 };
-static_assert(sizeof(QLds) == 1440, "QLds layout");
+static_assert(sizeof(QLds) == 2976, "QLds layout");
 
 struct __attribute__((aligned(16))) QTables {
     int      progress[16];   // macroblocks completed by wave w (monotonic over its rows)
@@ -58,6 +60,9 @@ struct __attribute__((aligned(16))) QTables {
 };
 
 typedef short s16x2 __attribute__((ext_vector_type(2)));
+typedef int v4i __attribute__((ext_vector_type(4)));   // native vectors: usable as inline-asm register operands
+typedef int v2i __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ int4 as_int4(v4i v) { return make_int4(v.x, v.y, v.z, v.w); }
 
 __device__ __forceinline__ int pk_add_sat(int a, int b)
 {
@@ -93,6 +98,34 @@ __device__ __forceinline__ uint32_t plane_row(int v, int b)
     return lo | (hi << 16);
 }
 
+// 16 samples of one row -> 48 bytes of RGB: 2x1 nearest chroma, integer formula of export_utils.c:300-302.
+__device__ __forceinline__ void rgb16(const uint4 yv, const uint2 cbv, const uint2 crv, v4i &o0, v4i &o1, v4i &o2)
+{
+    const uint32_t yw[4] = {yv.x, yv.y, yv.z, yv.w};
+    const uint32_t cbw[2] = {cbv.x, cbv.y}, crw[2] = {crv.x, crv.y};
+    uint32_t o[12];
+#pragma unroll
+    for (int g = 0; g < 4; g++) {       // four samples -> three dwords
+        uint32_t ch[12];
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const int x = g * 4 + t;
+            const int l = (yw[g] >> (t * 8)) & 255;
+            const int cb = (cbw[x >> 3] >> (((x >> 1) & 3) * 8)) & 255, cr = (crw[x >> 3] >> (((x >> 1) & 3) * 8)) & 255;
+            const int ly = (298 * l) >> 8;
+            ch[t * 3 + 0] = (uint32_t)clip255(ly + ((408 * cr) >> 8) - 222);
+            ch[t * 3 + 1] = (uint32_t)clip255(ly - ((100 * cb) >> 8) - ((208 * cr) >> 8) + 135);
+            ch[t * 3 + 2] = (uint32_t)clip255(ly + ((516 * cb) >> 8) - 276);
+        }
+        o[g * 3 + 0] = ch[0] | (ch[1] << 8) | (ch[2] << 16) | (ch[3] << 24);
+        o[g * 3 + 1] = ch[4] | (ch[5] << 8) | (ch[6] << 16) | (ch[7] << 24);
+        o[g * 3 + 2] = ch[8] | (ch[9] << 8) | (ch[10] << 16) | (ch[11] << 24);
+    }
+    o0 = v4i{(int)o[0], (int)o[1], (int)o[2], (int)o[3]};
+    o1 = v4i{(int)o[4], (int)o[5], (int)o[6], (int)o[7]};
+    o2 = v4i{(int)o[8], (int)o[9], (int)o[10], (int)o[11]};
+}
+
 // quad_perm DPP controls
 #define DPP_XOR1 0xB1  // [1,0,3,2]
 #define DPP_XOR2 0x4E  // [2,3,0,1]
@@ -118,7 +151,7 @@ __device__ __forceinline__ int had4_lanes(int x, int p, int idx, int addrP, int 
     return (idx == 1 || idx == 2) ? (P - Q) : (P + Q); // a+c, a-c, b-e, b+e
 }
 
-template <int NW>
+template <int NW, bool RGB>
 __global__ __launch_bounds__(NW * 64) void recon_quad_kernel(ReconArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -165,26 +198,39 @@ __global__ __launch_bounds__(NW * 64) void recon_quad_kernel(ReconArgs a)
 
     // Packed records are prefetched one macroblock ahead into the registers of the lanes that consume them:
     // every lane of the quarter reads the 32-byte header (same address: one fetch), lane j the 32 bytes of
-    // luma block j and, for j < 8, the 32 bytes of chroma block j.
-    int4 pH0, pH1, pLA, pLB, pCA, pCB;
+    // luma block j and, for j < 8, the 32 bytes of chroma block j (lanes 8-15 repeat their luma address).
+    // The loads and the plane stores are inline assembly so that the number of vector-memory operations
+    // between a prefetch and its use is fixed: a step that flushes a full output strip issues exactly VM_STORES stores after
+    // the twelve loads, any other step none, and the use is guarded by s_waitcnt vmcnt(VM_STORES) or vmcnt(0)
+    // accordingly -- the loads have landed, the stores of the step are still in flight.  (Left to the compiler, the wait became vmcnt(0) plus an immediate wait on the header.)
+    constexpr int VM_STORES = RGB ? 18 : 6;   // one full strip: 4 luma + 2 chroma (+ 12 RGB) 16-byte stores per lane
+    v2i pf[12];
+#pragma unroll
+    for (int i = 0; i < 12; i++) pf[i] = v2i{0, 0};
     auto prefetch = [&](int prow, int px, int lane_p) {
-        const int4 z = make_int4(0, 0, 0, 0);
-        pH0 = pH1 = pLA = pLB = pCA = pCB = z;
-        if (prow >= H) return;
         const int jj = lane_p & 15;
         const uint8_t *rec = fpacked + (size_t)(prow * W + px) * MVHP_MB_BYTES;
-        pH0 = *reinterpret_cast<const int4 *>(rec);
-        pH1 = *reinterpret_cast<const int4 *>(rec + 16);
-        pLA = *reinterpret_cast<const int4 *>(rec + MVHP_MB_HEADER_BYTES + jj * 32);
-        pLB = *reinterpret_cast<const int4 *>(rec + MVHP_MB_HEADER_BYTES + jj * 32 + 16);
-        if (jj < 8) {
-            pCA = *reinterpret_cast<const int4 *>(rec + MVHP_MB_HEADER_BYTES + (16 + jj) * 32);
-            pCB = *reinterpret_cast<const int4 *>(rec + MVHP_MB_HEADER_BYTES + (16 + jj) * 32 + 16);
-        }
+        const uint8_t *recL = rec + MVHP_MB_HEADER_BYTES + jj * 32;
+        const uint8_t *recC = rec + MVHP_MB_HEADER_BYTES + ((jj < 8) ? (16 + jj) : jj) * 32;
+        // 8-byte pieces: a v2i is the widest type whose halves the register-move asm below can name
+        asm volatile("global_load_dwordx2 %0, %1, off" : "=&v"(pf[0]) : "v"(rec) : "memory");
+        asm volatile("global_load_dwordx2 %0, %1, off offset:8" : "=&v"(pf[1]) : "v"(rec) : "memory");
+        asm volatile("global_load_dwordx2 %0, %1, off offset:16" : "=&v"(pf[2]) : "v"(rec) : "memory");
+        asm volatile("global_load_dwordx2 %0, %1, off offset:24" : "=&v"(pf[3]) : "v"(rec) : "memory");
+        asm volatile("global_load_dwordx2 %0, %1, off" : "=&v"(pf[4]) : "v"(recL) : "memory");
+        asm volatile("global_load_dwordx2 %0, %1, off offset:8" : "=&v"(pf[5]) : "v"(recL) : "memory");
+        asm volatile("global_load_dwordx2 %0, %1, off offset:16" : "=&v"(pf[6]) : "v"(recL) : "memory");
+        asm volatile("global_load_dwordx2 %0, %1, off offset:24" : "=&v"(pf[7]) : "v"(recL) : "memory");
+        asm volatile("global_load_dwordx2 %0, %1, off" : "=&v"(pf[8]) : "v"(recC) : "memory");
+        asm volatile("global_load_dwordx2 %0, %1, off offset:8" : "=&v"(pf[9]) : "v"(recC) : "memory");
+        asm volatile("global_load_dwordx2 %0, %1, off offset:16" : "=&v"(pf[10]) : "v"(recC) : "memory");
+        asm volatile("global_load_dwordx2 %0, %1, off offset:24" : "=&v"(pf[11]) : "v"(recC) : "memory");
     };
-    prefetch(wave, 0, lane_c);
+    if (wave < H) prefetch(wave, 0, lane_c);
+    asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
 
     int done = 0; // macroblocks completed by this wave
+    bool full_flush = false; // the previous step flushed a full strip: VM_STORES stores are younger than the prefetch
     for (int row = wave; row < H; row += NW) {
         const int pass = row / NW;
         const int up_base = ((wave == 0) ? (pass - 1) : pass) * W; // MBs the upper wave finished before its row (row-1)
@@ -202,10 +248,29 @@ __global__ __launch_bounds__(NW * 64) void recon_quad_kernel(ReconArgs a)
             uint8_t *line_cr = line_cb + W * 8;
             const bool A = mbx > 0, C = Bv && (mbx < W - 1), D = A && Bv;
 
-            const int4 cH0 = pH0, cH1 = pH1, cLA = pLA, cLB = pLB, cCA = pCA, cCB = pCB;
-            {   // next macroblock of this wave: same row, or the first of its next row
+            // wait for the prefetched record, then move it out of the prefetch registers -- the moves are part of
+            // the same asm block so that nothing can read those registers before the wait
+            v2i w[12];
+#define MVHP_WAIT_AND_TAKE(N)                                                                                          \
+            asm volatile("s_waitcnt vmcnt(%24)\n\t"                                                                    \
+                         "v_mov_b64 %0, %12\n\tv_mov_b64 %1, %13\n\tv_mov_b64 %2, %14\n\tv_mov_b64 %3, %15\n\t"        \
+                         "v_mov_b64 %4, %16\n\tv_mov_b64 %5, %17\n\tv_mov_b64 %6, %18\n\tv_mov_b64 %7, %19\n\t"        \
+                         "v_mov_b64 %8, %20\n\tv_mov_b64 %9, %21\n\tv_mov_b64 %10, %22\n\tv_mov_b64 %11, %23"           \
+                         : "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2]), "=&v"(w[3]), "=&v"(w[4]), "=&v"(w[5]),                \
+                           "=&v"(w[6]), "=&v"(w[7]), "=&v"(w[8]), "=&v"(w[9]), "=&v"(w[10]), "=&v"(w[11])               \
+                         : "v"(pf[0]), "v"(pf[1]), "v"(pf[2]), "v"(pf[3]), "v"(pf[4]), "v"(pf[5]),                      \
+                           "v"(pf[6]), "v"(pf[7]), "v"(pf[8]), "v"(pf[9]), "v"(pf[10]), "v"(pf[11]), "n"(N)             \
+                         : "memory")
+            if (full_flush) MVHP_WAIT_AND_TAKE(VM_STORES);
+            else MVHP_WAIT_AND_TAKE(0);
+#undef MVHP_WAIT_AND_TAKE
+            const int4 cH0 = make_int4(w[0].x, w[0].y, w[1].x, w[1].y), cH1 = make_int4(w[2].x, w[2].y, w[3].x, w[3].y);
+            const int4 cLA = make_int4(w[4].x, w[4].y, w[5].x, w[5].y), cLB = make_int4(w[6].x, w[6].y, w[7].x, w[7].y);
+            const int4 cCA = make_int4(w[8].x, w[8].y, w[9].x, w[9].y), cCB = make_int4(w[10].x, w[10].y, w[11].x, w[11].y);
+            {   // next macroblock of this wave: same row, or the first of its next row (none left: this one again)
                 int nrow = row, nx = mbx + 1;
                 if (nx >= W) { nrow = row + NW; nx = 0; }
+                if (nrow >= H) { nrow = row; nx = mbx; }
                 prefetch(nrow, nx, lane);
             }
             const uint32_t h0 = (uint32_t)cH0.x, h1 = (uint32_t)cH0.y, nz = (uint32_t)cH0.z;
@@ -648,46 +713,80 @@ __global__ __launch_bounds__(NW * 64) void recon_quad_kernel(ReconArgs a)
             WAVE_SYNC();
 
             // =====================================================================================
-            // write-out: lane j stores luma row j (16 B), chroma row j & 7 of plane j >> 3 (8 B) and, fused,
-            // the 16 RGB samples of row j (48 B) -- mb_to_rgb, export_utils.c:209-324
+            // write-out: the macroblock joins a 4-macroblock output strip in LDS (lane j copies luma row j and
+            // chroma row j & 7 of plane j >> 3); a full strip goes to HBM as 64-byte luma / 32-byte chroma row
+            // segments and, fused, 192 bytes of RGB per row -- mb_to_rgb, export_utils.c:209-324
             // =====================================================================================
+            const int mbi = mbx & 3;
             {
-                const uint4 yv = *reinterpret_cast<const uint4 *>(&Q.T[(j + 1) * 32 + 16]);
-                const uint2 cv = *reinterpret_cast<const uint2 *>(&Q.TC[j >> 3][((j & 7) + 1) * 16 + 8]);
-                if (valid) {
-                    *reinterpret_cast<uint4 *>(&fy[(size_t)(row * 16 + j) * pitch + mbx * 16]) = yv;
-                    *reinterpret_cast<uint2 *>(fy + plane_y + (size_t)(j >> 3) * plane_c + (size_t)(row * 8 + (j & 7)) * cpitch + mbx * 8) = cv;
-                }
-                if (frgb) {
-                    const uint2 cbv = *reinterpret_cast<const uint2 *>(&Q.TC[0][((j >> 1) + 1) * 16 + 8]);
-                    const uint2 crv = *reinterpret_cast<const uint2 *>(&Q.TC[1][((j >> 1) + 1) * 16 + 8]);
-                    const uint32_t yw[4] = {yv.x, yv.y, yv.z, yv.w};
-                    const uint32_t cbw[2] = {cbv.x, cbv.y}, crw[2] = {crv.x, crv.y};
-                    uint32_t o[12];
-#pragma unroll
-                    for (int g = 0; g < 4; g++) {       // four samples -> three dwords
-                        uint32_t ch[12];
-#pragma unroll
-                        for (int t = 0; t < 4; t++) {
-                            const int x = g * 4 + t;
-                            const int l = (yw[g] >> (t * 8)) & 255;
-                            const int cb = (cbw[x >> 3] >> (((x >> 1) & 3) * 8)) & 255, cr = (crw[x >> 3] >> (((x >> 1) & 3) * 8)) & 255;
-                            const int ly = (298 * l) >> 8;
-                            ch[t * 3 + 0] = (uint32_t)clip255(ly + ((408 * cr) >> 8) - 222);
-                            ch[t * 3 + 1] = (uint32_t)clip255(ly - ((100 * cb) >> 8) - ((208 * cr) >> 8) + 135);
-                            ch[t * 3 + 2] = (uint32_t)clip255(ly + ((516 * cb) >> 8) - 276);
-                        }
-                        o[g * 3 + 0] = ch[0] | (ch[1] << 8) | (ch[2] << 16) | (ch[3] << 24);
-                        o[g * 3 + 1] = ch[4] | (ch[5] << 8) | (ch[6] << 16) | (ch[7] << 24);
-                        o[g * 3 + 2] = ch[8] | (ch[9] << 8) | (ch[10] << 16) | (ch[11] << 24);
-                    }
+                *reinterpret_cast<uint4 *>(&Q.SY[j * 64 + mbi * 16]) = *reinterpret_cast<const uint4 *>(&Q.T[(j + 1) * 32 + 16]);
+                *reinterpret_cast<uint2 *>(&Q.SC[j >> 3][(j & 7) * 32 + mbi * 8]) =
+                    *reinterpret_cast<const uint2 *>(&Q.TC[j >> 3][((j & 7) + 1) * 16 + 8]);
+            }
+            full_flush = false;
+            if (mbi == 3 || mbx == W - 1) {
+                WAVE_SYNC();
+                const int x0 = mbx - mbi;              // strip origin, macroblock units
+                const int nmb = mbi + 1;
+                full_flush = (nmb == 4);
+                uint8_t *py = &fy[(size_t)(row * 16 + j) * pitch + x0 * 16];
+                uint8_t *pc = fy + plane_y + (size_t)(j >> 3) * plane_c + (size_t)(row * 8 + (j & 7)) * cpitch + x0 * 8;
+                uint8_t *prgb = RGB ? frgb + ((size_t)(row * 16 + j) * pitch + x0 * 16) * 3 : nullptr;
+                const uint4 *sy = reinterpret_cast<const uint4 *>(&Q.SY[j * 64]);
+                const uint4 *sc = reinterpret_cast<const uint4 *>(&Q.SC[j >> 3][(j & 7) * 32]);
+                const uint2 *scb = reinterpret_cast<const uint2 *>(&Q.SC[0][(j >> 1) * 32]);
+                const uint2 *scr = reinterpret_cast<const uint2 *>(&Q.SC[1][(j >> 1) * 32]);
+                if (full_flush) {
+                    // exactly VM_STORES store instructions (see the prefetch wait)
                     if (valid) {
-                        uint4 *dst = reinterpret_cast<uint4 *>(frgb + ((size_t)(row * 16 + j) * pitch + mbx * 16) * 3);
-                        dst[0] = make_uint4(o[0], o[1], o[2], o[3]);
-                        dst[1] = make_uint4(o[4], o[5], o[6], o[7]);
-                        dst[2] = make_uint4(o[8], o[9], o[10], o[11]);
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            const uint4 t = sy[k];
+                            const v4i tq = {(int)t.x, (int)t.y, (int)t.z, (int)t.w};
+                            asm volatile("global_store_dwordx4 %0, %1, off" : : "v"(py + k * 16), "v"(tq) : "memory");
+                        }
+#pragma unroll
+                        for (int k = 0; k < 2; k++) {
+                            const uint4 t = sc[k];
+                            const v4i tq = {(int)t.x, (int)t.y, (int)t.z, (int)t.w};
+                            asm volatile("global_store_dwordx4 %0, %1, off" : : "v"(pc + k * 16), "v"(tq) : "memory");
+                        }
+                    }
+                    if (RGB) {
+#pragma unroll 1
+                        for (int k = 0; k < 4; k++) {
+                            const uint4 yv = sy[k];
+                            const uint2 cbv = scb[k], crv = scr[k];
+                            v4i o0, o1, o2;
+                            rgb16(yv, cbv, crv, o0, o1, o2);
+                            if (valid) {
+                                uint8_t *dst = prgb + k * 48;
+                                asm volatile("global_store_dwordx4 %0, %1, off" : : "v"(dst), "v"(o0) : "memory");
+                                asm volatile("global_store_dwordx4 %0, %1, off offset:16" : : "v"(dst), "v"(o1) : "memory");
+                                asm volatile("global_store_dwordx4 %0, %1, off offset:32" : : "v"(dst), "v"(o2) : "memory");
+                            }
+                        }
+                    }
+                } else {
+                    // short strip at the right picture edge (W % 4 != 0): per macroblock, compiler-counted
+                    for (int k = 0; k < nmb; k++) {
+                        const uint4 yv = sy[k];
+                        const uint2 cv = *reinterpret_cast<const uint2 *>(&Q.SC[j >> 3][(j & 7) * 32 + k * 8]);
+                        if (valid) {
+                            *reinterpret_cast<uint4 *>(py + k * 16) = yv;
+                            *reinterpret_cast<uint2 *>(pc + k * 8) = cv;
+                        }
+                        if (RGB) {
+                            v4i o0, o1, o2;
+                            rgb16(yv, scb[k], scr[k], o0, o1, o2);
+                            if (valid) {
+                                v4i *dst = reinterpret_cast<v4i *>(prgb + k * 48);
+                                dst[0] = o0; dst[1] = o1; dst[2] = o2;
+                            }
+                        }
                     }
                 }
+                WAVE_SYNC();
             }
 
             // =====================================================================================
@@ -731,31 +830,25 @@ size_t recon_quad_lds_bytes(int width_mbs, int nw)
     return sizeof(QTables) + (size_t)4 * width_mbs * 32 + (size_t)nw * 4 * sizeof(QLds);
 }
 
+template <int NW, bool RGB>
+static hipError_t launch_quad_one(const ReconArgs &a, hipStream_t stream)
+{
+    const size_t lds = recon_quad_lds_bytes(a.width_mbs, NW);
+    const int groups = (a.n_frames + 3) / 4;
+    hipError_t e = hipFuncSetAttribute((const void *)recon_quad_kernel<NW, RGB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((recon_quad_kernel<NW, RGB>), dim3(groups), dim3(NW * 64), lds, stream, a);
+    return hipGetLastError();
+}
+
 hipError_t launch_recon_quad(const ReconArgs &a, int nw, hipStream_t stream)
 {
-    const size_t lds = recon_quad_lds_bytes(a.width_mbs, nw);
-    const int groups = (a.n_frames + 3) / 4;
-    hipError_t e = hipSuccess;
+    const bool rgb = a.rgb != nullptr;
     switch (nw) {
-    case 4:
-        e = hipFuncSetAttribute((const void *)recon_quad_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(recon_quad_kernel<4>, dim3(groups), dim3(4 * 64), lds, stream, a);
-        break;
-    case 8:
-        e = hipFuncSetAttribute((const void *)recon_quad_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(recon_quad_kernel<8>, dim3(groups), dim3(8 * 64), lds, stream, a);
-        break;
-    case 16:
-        e = hipFuncSetAttribute((const void *)recon_quad_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(recon_quad_kernel<16>, dim3(groups), dim3(16 * 64), lds, stream, a);
-        break;
-    default:
-        return hipErrorInvalidValue;
+    case 4: return rgb ? launch_quad_one<4, true>(a, stream) : launch_quad_one<4, false>(a, stream);
+    case 8: return rgb ? launch_quad_one<8, true>(a, stream) : launch_quad_one<8, false>(a, stream);
+    default: return hipErrorInvalidValue;
     }
-    return hipGetLastError();
 }
 
 } // namespace mvhp
