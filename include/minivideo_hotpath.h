@@ -174,7 +174,8 @@ MVHP_EXPORT int  mvhp_time_recon(mvhp_ctx_t *ctx, const mvhp_stream_params_t *p,
 MVHP_EXPORT int  mvhp_set_fused_color(mvhp_ctx_t *ctx, int on);
 
 /* Tuning knob (speed only, never results): waves per picture workgroup
- * (4, 8 or 16); 0 = choose from batch size. */
+ * (4, 6, 8, 12 or 16; a layout that is not built for the value takes the next smaller one);
+ * 0 = choose from batch size. */
 MVHP_EXPORT int  mvhp_set_waves_per_picture(mvhp_ctx_t *ctx, int waves);
 
 /* Tuning knob (speed only, never results): how pictures map onto workgroups.

@@ -138,7 +138,7 @@ MVHP_EXPORT void mvhp_destroy(mvhp_ctx_t *c)
 
 MVHP_EXPORT int mvhp_set_waves_per_picture(mvhp_ctx_t *c, int waves)
 {
-    if (!c || !(waves == 0 || waves == 4 || waves == 8 || waves == 16)) return MVHP_FAILURE;
+    if (!c || !(waves == 0 || waves == 4 || waves == 6 || waves == 8 || waves == 12 || waves == 16)) return MVHP_FAILURE;
     c->waves = waves;
     return MVHP_SUCCESS;
 }
@@ -184,16 +184,23 @@ static int pick_waves(const mvhp_ctx *c, const mvhp_stream_params_t *p, int n_fr
 {
     int nw = c->waves;
     if (quad) {
-        // speed only: 8-wave workgroups fit one to a CU (LDS), 4-wave workgroups two
-        // (the quad kernel is built for 4 and 8 waves: at 16 its register budget would force spills)
-        if (nw == 0 || nw > 8) nw = 8;
-        while (nw > 4 && (nw / 2) >= (int)p->height_mbs) nw /= 2;
-        while (nw > 4 && mvhp::recon_quad_lds_bytes((int)p->width_mbs, nw) > c->max_lds) nw /= 2;
-        return nw;
+        // speed only: the quad kernel is built for 4, 6, 8 and 12 waves (at 16 its register budget would force
+        // spills); 6-wave workgroups fit two to a CU = 12 waves per CU, the most its registers allow
+        static const int opts[4] = {12, 8, 6, 4};
+        if (nw == 0) nw = 6;
+        for (int k = 0; k < 4; k++) {
+            const int o = opts[k];
+            if (o > nw) continue;
+            if (o > 4 && ((o + 1) / 2 >= (int)p->height_mbs || mvhp::recon_quad_lds_bytes((int)p->width_mbs, o) > c->max_lds)) continue;
+            return o;
+        }
+        return 4;
     }
     // speed only (DESIGN.md "waves per picture"): 8-wave workgroups fit three to a CU (LDS) = 24 waves/CU,
     // 16-wave workgroups one to a CU; small batches need the wider workgroup to occupy the chip.
     if (nw == 0) nw = (n_frames >= 384) ? 8 : 16;
+    if (nw == 6) nw = 4;
+    if (nw == 12) nw = 8;
     while (nw > 4 && (nw / 2) >= (int)p->height_mbs) nw /= 2;
     while (nw > 4 && mvhp::recon_lds_bytes((int)p->width_mbs, nw) > c->max_lds) nw /= 2;
     return nw;

@@ -40,11 +40,9 @@ struct __attribute__((aligned(16))) QLds {
     uint8_t Lcol[16];        // compact left neighbour column (luma)
     uint8_t LcolC[2][8];     // compact left neighbour columns (Cb, Cr)
     uint8_t E8[32];          // filtered Intra8x8 edge, see recon_device.h mode_entry()
-    uint8_t SY[16 * 64];     // output strip: four macroblocks of reconstructed luma, flushed as 64-byte row segments
-    uint8_t SC[2][8 * 32];   // output strip: four macroblocks of Cb / Cr (32-byte row segments)
-    uint8_t pad[16];         // 2976 B: quarters land 744 dwords apart (different banks)
+    uint8_t pad[16];         // 1440 B: quarters land 360 dwords apart (different banks)
 };
-static_assert(sizeof(QLds) == 2976, "QLds layout");
+static_assert(sizeof(QLds) == 1440, "QLds layout");
 
 struct __attribute__((aligned(16))) QTables {
     int      progress[16];   // macroblocks completed by wave w (monotonic over its rows)
@@ -200,10 +198,12 @@ __global__ __launch_bounds__(NW * 64) void recon_quad_kernel(ReconArgs a)
     // every lane of the quarter reads the 32-byte header (same address: one fetch), lane j the 32 bytes of
     // luma block j and, for j < 8, the 32 bytes of chroma block j (lanes 8-15 repeat their luma address).
     // The loads and the plane stores are inline assembly so that the number of vector-memory operations
-    // between a prefetch and its use is fixed: a step that flushes a full output strip issues exactly VM_STORES stores after
-    // the twelve loads, any other step none, and the use is guarded by s_waitcnt vmcnt(VM_STORES) or vmcnt(0)
-    // accordingly -- the loads have landed, the stores of the step are still in flight.  (Left to the compiler, the wait became vmcnt(0) plus an immediate wait on the header.)
-    constexpr int VM_STORES = RGB ? 18 : 6;   // one full strip: 4 luma + 2 chroma (+ 12 RGB) 16-byte stores per lane
+    // between a prefetch and its use is fixed: a step issues exactly 0, VM_PAIR or VM_QUAD stores after the twelve loads
+    // (`n_st`), and the use is guarded by s_waitcnt vmcnt(n_st) -- the loads have landed, the stores of the step are still in flight.  (Left to the compiler, the wait became vmcnt(0) plus an immediate wait on the header.)
+    // Each asm store carries two wait states: a VALU write of the data registers of a >64-bit store right behind it
+    // is a hardware hazard the compiler cannot see through inline assembly.
+    constexpr int VM_PAIR = RGB ? 8 : 2;      // a macroblock pair: 2 luma (+ 6 RGB) 16-byte stores per lane
+    constexpr int VM_QUAD = VM_PAIR + 2;      // ... plus the 32-byte chroma rows of four macroblocks
     v2i pf[12];
 #pragma unroll
     for (int i = 0; i < 12; i++) pf[i] = v2i{0, 0};
@@ -230,7 +230,12 @@ __global__ __launch_bounds__(NW * 64) void recon_quad_kernel(ReconArgs a)
     asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
 
     int done = 0; // macroblocks completed by this wave
-    bool full_flush = false; // the previous step flushed a full strip: VM_STORES stores are younger than the prefetch
+    int n_st = 0;  // asm stores the previous step issued after its prefetch (0 also when the compiler counted them)
+    // Output strips, in registers: 32 bytes is the granularity of HBM writes, so luma (16 B per macroblock row) and
+    // RGB (48 B) leave in pairs of macroblocks and chroma (8 B) in fours.
+    v4i st_y = {0, 0, 0, 0};                       // luma row j of the even macroblock of the pair
+    v2i st_c0 = {0, 0}, st_c1 = st_c0, st_c2 = st_c0;   // chroma row (j & 7) of plane (j >> 3), macroblocks 0..2 of the four
+    uint2 st_cb = make_uint2(0u, 0u), st_cr = st_cb;    // chroma rows (j >> 1) of the even macroblock, for its RGB
     for (int row = wave; row < H; row += NW) {
         const int pass = row / NW;
         const int up_base = ((wave == 0) ? (pass - 1) : pass) * W; // MBs the upper wave finished before its row (row-1)
@@ -261,7 +266,8 @@ __global__ __launch_bounds__(NW * 64) void recon_quad_kernel(ReconArgs a)
                          : "v"(pf[0]), "v"(pf[1]), "v"(pf[2]), "v"(pf[3]), "v"(pf[4]), "v"(pf[5]),                      \
                            "v"(pf[6]), "v"(pf[7]), "v"(pf[8]), "v"(pf[9]), "v"(pf[10]), "v"(pf[11]), "n"(N)             \
                          : "memory")
-            if (full_flush) MVHP_WAIT_AND_TAKE(VM_STORES);
+            if (n_st == VM_QUAD) MVHP_WAIT_AND_TAKE(VM_QUAD);
+            else if (n_st == VM_PAIR) MVHP_WAIT_AND_TAKE(VM_PAIR);
             else MVHP_WAIT_AND_TAKE(0);
 #undef MVHP_WAIT_AND_TAKE
             const int4 cH0 = make_int4(w[0].x, w[0].y, w[1].x, w[1].y), cH1 = make_int4(w[2].x, w[2].y, w[3].x, w[3].y);
@@ -713,80 +719,93 @@ __global__ __launch_bounds__(NW * 64) void recon_quad_kernel(ReconArgs a)
             WAVE_SYNC();
 
             // =====================================================================================
-            // write-out: the macroblock joins a 4-macroblock output strip in LDS (lane j copies luma row j and
-            // chroma row j & 7 of plane j >> 3); a full strip goes to HBM as 64-byte luma / 32-byte chroma row
-            // segments and, fused, 192 bytes of RGB per row -- mb_to_rgb, export_utils.c:209-324
+            // write-out: lane j holds luma row j (16 B) and chroma row j & 7 of plane j >> 3 (8 B) of this
+            // macroblock.  Even macroblocks are parked in registers; odd ones leave with their left neighbour as
+            // 32-byte luma and 96-byte RGB row segments (mb_to_rgb, export_utils.c:209-324, fused), every fourth
+            // one also takes 32 bytes of chroma along.
             // =====================================================================================
-            const int mbi = mbx & 3;
             {
-                *reinterpret_cast<uint4 *>(&Q.SY[j * 64 + mbi * 16]) = *reinterpret_cast<const uint4 *>(&Q.T[(j + 1) * 32 + 16]);
-                *reinterpret_cast<uint2 *>(&Q.SC[j >> 3][(j & 7) * 32 + mbi * 8]) =
-                    *reinterpret_cast<const uint2 *>(&Q.TC[j >> 3][((j & 7) + 1) * 16 + 8]);
-            }
-            full_flush = false;
-            if (mbi == 3 || mbx == W - 1) {
-                WAVE_SYNC();
-                const int x0 = mbx - mbi;              // strip origin, macroblock units
-                const int nmb = mbi + 1;
-                full_flush = (nmb == 4);
-                uint8_t *py = &fy[(size_t)(row * 16 + j) * pitch + x0 * 16];
-                uint8_t *pc = fy + plane_y + (size_t)(j >> 3) * plane_c + (size_t)(row * 8 + (j & 7)) * cpitch + x0 * 8;
-                uint8_t *prgb = RGB ? frgb + ((size_t)(row * 16 + j) * pitch + x0 * 16) * 3 : nullptr;
-                const uint4 *sy = reinterpret_cast<const uint4 *>(&Q.SY[j * 64]);
-                const uint4 *sc = reinterpret_cast<const uint4 *>(&Q.SC[j >> 3][(j & 7) * 32]);
-                const uint2 *scb = reinterpret_cast<const uint2 *>(&Q.SC[0][(j >> 1) * 32]);
-                const uint2 *scr = reinterpret_cast<const uint2 *>(&Q.SC[1][(j >> 1) * 32]);
-                if (full_flush) {
-                    // exactly VM_STORES store instructions (see the prefetch wait)
+                const int mbi = mbx & 3;
+                const uint4 yv = *reinterpret_cast<const uint4 *>(&Q.T[(j + 1) * 32 + 16]);
+                const uint2 cv = *reinterpret_cast<const uint2 *>(&Q.TC[j >> 3][((j & 7) + 1) * 16 + 8]);
+                uint2 cbv = make_uint2(0u, 0u), crv = cbv;
+                if (RGB) {
+                    cbv = *reinterpret_cast<const uint2 *>(&Q.TC[0][((j >> 1) + 1) * 16 + 8]);
+                    crv = *reinterpret_cast<const uint2 *>(&Q.TC[1][((j >> 1) + 1) * 16 + 8]);
+                }
+                const v4i yq = {(int)yv.x, (int)yv.y, (int)yv.z, (int)yv.w};
+                const v2i cq = {(int)cv.x, (int)cv.y};
+                uint8_t *py = &fy[(size_t)(row * 16 + j) * pitch + (mbx & ~1) * 16];
+                uint8_t *pc = fy + plane_y + (size_t)(j >> 3) * plane_c + (size_t)(row * 8 + (j & 7)) * cpitch + (mbx & ~3) * 8;
+                uint8_t *prgb = RGB ? frgb + ((size_t)(row * 16 + j) * pitch + (mbx & ~1) * 16) * 3 : nullptr;
+                n_st = 0;
+                if (mbx & 1) {
+                    // ---- pair flush: exactly VM_PAIR store instructions ----
                     if (valid) {
-#pragma unroll
-                        for (int k = 0; k < 4; k++) {
-                            const uint4 t = sy[k];
-                            const v4i tq = {(int)t.x, (int)t.y, (int)t.z, (int)t.w};
-                            asm volatile("global_store_dwordx4 %0, %1, off" : : "v"(py + k * 16), "v"(tq) : "memory");
+                        asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" : : "v"(py), "v"(st_y) : "memory");
+                        asm volatile("global_store_dwordx4 %0, %1, off offset:16\n\ts_nop 1" : : "v"(py), "v"(yq) : "memory");
+                    }
+                    if (RGB) {
+                        v4i a0, a1, a2;
+                        const uint4 y0 = make_uint4((uint32_t)st_y.x, (uint32_t)st_y.y, (uint32_t)st_y.z, (uint32_t)st_y.w);
+                        rgb16(y0, st_cb, st_cr, a0, a1, a2);
+                        if (valid) {
+                            asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" : : "v"(prgb), "v"(a0) : "memory");
+                            asm volatile("global_store_dwordx4 %0, %1, off offset:16\n\ts_nop 1" : : "v"(prgb), "v"(a1) : "memory");
+                            asm volatile("global_store_dwordx4 %0, %1, off offset:32\n\ts_nop 1" : : "v"(prgb), "v"(a2) : "memory");
                         }
-#pragma unroll
-                        for (int k = 0; k < 2; k++) {
-                            const uint4 t = sc[k];
-                            const v4i tq = {(int)t.x, (int)t.y, (int)t.z, (int)t.w};
-                            asm volatile("global_store_dwordx4 %0, %1, off" : : "v"(pc + k * 16), "v"(tq) : "memory");
+                        rgb16(yv, cbv, crv, a0, a1, a2);
+                        if (valid) {
+                            asm volatile("global_store_dwordx4 %0, %1, off offset:48\n\ts_nop 1" : : "v"(prgb), "v"(a0) : "memory");
+                            asm volatile("global_store_dwordx4 %0, %1, off offset:64\n\ts_nop 1" : : "v"(prgb), "v"(a1) : "memory");
+                            asm volatile("global_store_dwordx4 %0, %1, off offset:80\n\ts_nop 1" : : "v"(prgb), "v"(a2) : "memory");
+                        }
+                    }
+                    n_st = VM_PAIR;
+                    if (mbi == 3) {
+                        // ---- chroma of four macroblocks: exactly two more store instructions ----
+                        const v4i c01 = {st_c0.x, st_c0.y, st_c1.x, st_c1.y}, c23 = {st_c2.x, st_c2.y, cq.x, cq.y};
+                        if (valid) {
+                            asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" : : "v"(pc), "v"(c01) : "memory");
+                            asm volatile("global_store_dwordx4 %0, %1, off offset:16\n\ts_nop 1" : : "v"(pc), "v"(c23) : "memory");
+                        }
+                        n_st = VM_QUAD;
+                    } else {
+                        st_c1 = cq;
+                        if (mbx == W - 1) { // W % 4 == 2: two macroblocks of chroma left (compiler-counted stores)
+                            if (valid) {
+                                *reinterpret_cast<v2i *>(pc) = st_c0;
+                                *reinterpret_cast<v2i *>(pc + 8) = st_c1;
+                            }
+                            n_st = 0;
+                        }
+                    }
+                } else if (mbx == W - 1) {
+                    // ---- odd picture width: the last macroblock leaves alone (compiler-counted stores) ----
+                    if (valid) {
+                        *reinterpret_cast<v4i *>(py) = yq;
+                        if (mbi == 0) *reinterpret_cast<v2i *>(pc) = cq;
+                        else { // mbi == 2
+                            *reinterpret_cast<v2i *>(pc) = st_c0;
+                            *reinterpret_cast<v2i *>(pc + 8) = st_c1;
+                            *reinterpret_cast<v2i *>(pc + 16) = cq;
                         }
                     }
                     if (RGB) {
-#pragma unroll 1
-                        for (int k = 0; k < 4; k++) {
-                            const uint4 yv = sy[k];
-                            const uint2 cbv = scb[k], crv = scr[k];
-                            v4i o0, o1, o2;
-                            rgb16(yv, cbv, crv, o0, o1, o2);
-                            if (valid) {
-                                uint8_t *dst = prgb + k * 48;
-                                asm volatile("global_store_dwordx4 %0, %1, off" : : "v"(dst), "v"(o0) : "memory");
-                                asm volatile("global_store_dwordx4 %0, %1, off offset:16" : : "v"(dst), "v"(o1) : "memory");
-                                asm volatile("global_store_dwordx4 %0, %1, off offset:32" : : "v"(dst), "v"(o2) : "memory");
-                            }
+                        v4i a0, a1, a2;
+                        rgb16(yv, cbv, crv, a0, a1, a2);
+                        if (valid) {
+                            v4i *dst = reinterpret_cast<v4i *>(prgb);
+                            dst[0] = a0; dst[1] = a1; dst[2] = a2;
                         }
                     }
                 } else {
-                    // short strip at the right picture edge (W % 4 != 0): per macroblock, compiler-counted
-                    for (int k = 0; k < nmb; k++) {
-                        const uint4 yv = sy[k];
-                        const uint2 cv = *reinterpret_cast<const uint2 *>(&Q.SC[j >> 3][(j & 7) * 32 + k * 8]);
-                        if (valid) {
-                            *reinterpret_cast<uint4 *>(py + k * 16) = yv;
-                            *reinterpret_cast<uint2 *>(pc + k * 8) = cv;
-                        }
-                        if (RGB) {
-                            v4i o0, o1, o2;
-                            rgb16(yv, scb[k], scr[k], o0, o1, o2);
-                            if (valid) {
-                                v4i *dst = reinterpret_cast<v4i *>(prgb + k * 48);
-                                dst[0] = o0; dst[1] = o1; dst[2] = o2;
-                            }
-                        }
-                    }
+                    // ---- even macroblock: park ----
+                    st_y = yq;
+                    st_cb = cbv;
+                    st_cr = crv;
+                    if (mbi == 0) st_c0 = cq; else st_c2 = cq;
                 }
-                WAVE_SYNC();
             }
 
             // =====================================================================================
@@ -846,7 +865,9 @@ hipError_t launch_recon_quad(const ReconArgs &a, int nw, hipStream_t stream)
     const bool rgb = a.rgb != nullptr;
     switch (nw) {
     case 4: return rgb ? launch_quad_one<4, true>(a, stream) : launch_quad_one<4, false>(a, stream);
+    case 6: return rgb ? launch_quad_one<6, true>(a, stream) : launch_quad_one<6, false>(a, stream);
     case 8: return rgb ? launch_quad_one<8, true>(a, stream) : launch_quad_one<8, false>(a, stream);
+    case 12: return rgb ? launch_quad_one<12, true>(a, stream) : launch_quad_one<12, false>(a, stream);
     default: return hipErrorInvalidValue;
     }
 }

@@ -18,10 +18,10 @@ def regs(tok):
 def check(L, name):
     """L = the lines of one kernel."""
     waits = [i for i, l in enumerate(L) if re.search(r's_waitcnt vmcnt\(\d+\)', l) and 'v_mov_b64 ' in L[i + 1]]
-    assert len(waits) == 2, (name, waits)
+    assert len(waits) == 3, (name, waits)
     counts = sorted(int(re.search(r'vmcnt\((\d+)\)', L[w]).group(1)) for w in waits)
-    assert counts[0] == 0, (name, counts)
-    n_expect = counts[1]
+    assert counts[0] == 0 and counts[2] == counts[1] + 2, (name, counts)
+    n_expect = counts[2]
     w0 = min(waits)
     # the macroblock loop: the nearest label above the waits that a later instruction branches back to
     labi, back = None, []
@@ -63,9 +63,8 @@ def check(L, name):
     # the two wait blocks themselves read the prefetch registers (that is their job); nothing else may
     bad = [(i, l) for i, l in bad if not any(w < i <= w + 12 for w in waits)]
     assert not bad, (name, bad[:5])
-    # the RGB stores sit in a 4-trip loop (one trip per macroblock of the strip): 3 static = 12 dynamic
-    dynamic = asm_stores if n_expect == 6 else 6 + 4 * (asm_stores - 6)
-    assert dynamic == n_expect, (name, asm_stores, n_expect)
+    # every asm store of the loop lies on the path of the step that parks nothing: pair flush + chroma flush
+    assert asm_stores == n_expect, (name, asm_stores, n_expect)
     return n_expect, len(dest)
 
 
