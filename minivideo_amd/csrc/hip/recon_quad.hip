@@ -96,32 +96,62 @@ __device__ __forceinline__ uint32_t plane_row(int v, int b)
     return lo | (hi << 16);
 }
 
-// 16 samples of one row -> 48 bytes of RGB: 2x1 nearest chroma, integer formula of export_utils.c:300-302.
+// 16 samples of one row -> 48 bytes of RGB: 2x1 nearest chroma and the integer formula of export_utils.c:300-302,
+// in packed 16-bit arithmetic (two samples per instruction).  The reference's products are rewritten so that they
+// fit 16 bits -- (298 l) >> 8 == (149 l) >> 7, (408 c) >> 8 == (204 c) >> 7, (516 c) >> 8 == (129 c) >> 6 for every
+// byte l, c; 100 c and 208 c fit as they are -- and every sum stays inside int16, so v_sat_pk_u8_i16 is the clip.
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ u16x2 bytes01(uint32_t w) { return __builtin_bit_cast(u16x2, __builtin_amdgcn_perm(0u, w, 0x0c010c00u)); }
+__device__ __forceinline__ u16x2 bytes23(uint32_t w) { return __builtin_bit_cast(u16x2, __builtin_amdgcn_perm(0u, w, 0x0c030c02u)); }
+__device__ __forceinline__ uint32_t sat_pk_u8v(s16x2 v) { return sat_pk_u8(__builtin_bit_cast(int, v)); }
+// four samples (one luma word, their two chroma samples as a 16-bit pair per plane) -> three dwords of RGB
+__device__ __forceinline__ void rgb4(uint32_t yw, u16x2 cb, u16x2 cr, int &d0, int &d1, int &d2)
+{
+    const s16x2 rt = __builtin_bit_cast(s16x2, (u16x2)((cr * (unsigned short)204) >> 7)) - (short)222;
+    const s16x2 gt = (short)135 - __builtin_bit_cast(s16x2, (u16x2)((cb * (unsigned short)100) >> 8)) -
+                     __builtin_bit_cast(s16x2, (u16x2)((cr * (unsigned short)208) >> 8));
+    const s16x2 bt = __builtin_bit_cast(s16x2, (u16x2)((cb * (unsigned short)129) >> 6)) - (short)276;
+    const s16x2 ly01 = __builtin_bit_cast(s16x2, (u16x2)((bytes01(yw) * (unsigned short)149) >> 7));
+    const s16x2 ly23 = __builtin_bit_cast(s16x2, (u16x2)((bytes23(yw) * (unsigned short)149) >> 7));
+    const s16x2 rtl = __builtin_shufflevector(rt, rt, 0, 0), rth = __builtin_shufflevector(rt, rt, 1, 1);
+    const s16x2 gtl = __builtin_shufflevector(gt, gt, 0, 0), gth = __builtin_shufflevector(gt, gt, 1, 1);
+    const s16x2 btl = __builtin_shufflevector(bt, bt, 0, 0), bth = __builtin_shufflevector(bt, bt, 1, 1);
+    const uint32_t RA = sat_pk_u8v(ly01 + rtl), GA = sat_pk_u8v(ly01 + gtl), BA = sat_pk_u8v(ly01 + btl);
+    const uint32_t RB = sat_pk_u8v(ly23 + rth), GB = sat_pk_u8v(ly23 + gth), BB = sat_pk_u8v(ly23 + bth);
+    const uint32_t W1 = GA | (BA << 16), W2 = RB | (GB << 16);
+    d0 = (int)__builtin_amdgcn_perm(W1, RA, 0x01060400u);   // R0 G0 B0 R1
+    d1 = (int)__builtin_amdgcn_perm(W2, W1, 0x06040301u);   // G1 B1 R2 G2
+    d2 = (int)__builtin_amdgcn_perm(BB, W2, 0x05030104u);   // B2 R3 G3 B3
+}
 __device__ __forceinline__ void rgb16(const uint4 yv, const uint2 cbv, const uint2 crv, v4i &o0, v4i &o1, v4i &o2)
 {
-    const uint32_t yw[4] = {yv.x, yv.y, yv.z, yv.w};
-    const uint32_t cbw[2] = {cbv.x, cbv.y}, crw[2] = {crv.x, crv.y};
-    uint32_t o[12];
-#pragma unroll
-    for (int g = 0; g < 4; g++) {       // four samples -> three dwords
-        uint32_t ch[12];
-#pragma unroll
-        for (int t = 0; t < 4; t++) {
-            const int x = g * 4 + t;
-            const int l = (yw[g] >> (t * 8)) & 255;
-            const int cb = (cbw[x >> 3] >> (((x >> 1) & 3) * 8)) & 255, cr = (crw[x >> 3] >> (((x >> 1) & 3) * 8)) & 255;
-            const int ly = (298 * l) >> 8;
-            ch[t * 3 + 0] = (uint32_t)clip255(ly + ((408 * cr) >> 8) - 222);
-            ch[t * 3 + 1] = (uint32_t)clip255(ly - ((100 * cb) >> 8) - ((208 * cr) >> 8) + 135);
-            ch[t * 3 + 2] = (uint32_t)clip255(ly + ((516 * cb) >> 8) - 276);
-        }
-        o[g * 3 + 0] = ch[0] | (ch[1] << 8) | (ch[2] << 16) | (ch[3] << 24);
-        o[g * 3 + 1] = ch[4] | (ch[5] << 8) | (ch[6] << 16) | (ch[7] << 24);
-        o[g * 3 + 2] = ch[8] | (ch[9] << 8) | (ch[10] << 16) | (ch[11] << 24);
-    }
-    o0 = v4i{(int)o[0], (int)o[1], (int)o[2], (int)o[3]};
-    o1 = v4i{(int)o[4], (int)o[5], (int)o[6], (int)o[7]};
-    o2 = v4i{(int)o[8], (int)o[9], (int)o[10], (int)o[11]};
+    int d[12];
+    rgb4(yv.x, bytes01(cbv.x), bytes01(crv.x), d[0], d[1], d[2]);
+    rgb4(yv.y, bytes23(cbv.x), bytes23(crv.x), d[3], d[4], d[5]);
+    rgb4(yv.z, bytes01(cbv.y), bytes01(crv.y), d[6], d[7], d[8]);
+    rgb4(yv.w, bytes23(cbv.y), bytes23(crv.y), d[9], d[10], d[11]);
+    o0 = v4i{d[0], d[1], d[2], d[3]};
+    o1 = v4i{d[4], d[5], d[6], d[7]};
+    o2 = v4i{d[8], d[9], d[10], d[11]};
+}
+
+// Plane-prediction gradient (h264_intra_prediction.c:2064-2080, :2491-2504): sum over i of (i+1) * (e[h+i] - e[h-2-i])
+// with e[-1] = the corner, for 16 edge samples (h = 8, i < 8) as four byte dot products.
+__device__ __forceinline__ int plane_grad16(const uint4 e, uint32_t cor)
+{
+    const uint32_t pos = __builtin_amdgcn_udot4(e.w, 0x08070605u, __builtin_amdgcn_udot4(e.z, 0x04030201u, 0u, false), false);
+    const uint32_t e3456 = __builtin_amdgcn_alignbyte(e.y, e.x, 3);   // e[3], e[4], e[5], e[6]
+    const uint32_t c012 = (e.x << 8) | cor;                           // corner, e[0], e[1], e[2]
+    const uint32_t neg = __builtin_amdgcn_udot4(c012, 0x05060708u, __builtin_amdgcn_udot4(e3456, 0x01020304u, 0u, false), false);
+    return (int)pos - (int)neg;
+}
+// ... for 8 edge samples (h = 4, i < 4)
+__device__ __forceinline__ int plane_grad8(const uint2 e, uint32_t cor)
+{
+    const uint32_t pos = __builtin_amdgcn_udot4(e.y, 0x04030201u, 0u, false);
+    const uint32_t c012 = (e.x << 8) | cor;                           // corner, e[0], e[1], e[2]
+    const uint32_t neg = __builtin_amdgcn_udot4(c012, 0x01020304u, 0u, false);
+    return (int)pos - (int)neg;
 }
 
 // quad_perm DPP controls
@@ -149,8 +179,9 @@ __device__ __forceinline__ int had4_lanes(int x, int p, int idx, int addrP, int 
     return (idx == 1 || idx == 2) ? (P - Q) : (P + Q); // a+c, a-c, b-e, b+e
 }
 
+// 128 VGPRs = four waves per SIMD: two 8-wave workgroups (or four 4-wave ones) per CU; LDS allows as many.
 template <int NW, bool RGB>
-__global__ __launch_bounds__(NW * 64) void recon_quad_kernel(ReconArgs a)
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW == 12 ? 3 : 4, NW == 12 ? 3 : 4))) void recon_quad_kernel(ReconArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int W = a.width_mbs, H = a.height_mbs;
@@ -182,7 +213,7 @@ __global__ __launch_bounds__(NW * 64) void recon_quad_kernel(ReconArgs a)
     __syncthreads();
 
     const int pitch = W * 16, cpitch = W * 8;
-    const size_t plane_y = (size_t)W * H * 256, plane_c = (size_t)W * H * 64;
+    const uint32_t plane_y = (uint32_t)W * H * 256, plane_c = (uint32_t)W * H * 64;
     const int up_wave = (wave + NW - 1) % NW;
 
     // this lane's picture
@@ -190,9 +221,17 @@ __global__ __launch_bounds__(NW * 64) void recon_quad_kernel(ReconArgs a)
     const int frame_raw = (int)blockIdx.x * 4 + q_c;
     const bool valid = frame_raw < a.n_frames;            // a short last workgroup repeats the last picture, stores off
     const int frame = min(frame_raw, a.n_frames - 1);
-    const uint8_t *fpacked = a.packed + (size_t)frame * W * H * MVHP_MB_BYTES;
-    uint8_t *fy = a.yuv + (size_t)frame * W * H * 384;
-    uint8_t *frgb = a.rgb ? a.rgb + (size_t)frame * W * H * 768 : nullptr;
+    // Addresses: a scalar base per workgroup (its first picture) plus a 32-bit per-lane offset -- four pictures of
+    // the largest supported size (1024 x 1024 macroblocks) span < 4 GiB in every buffer.
+    const uint32_t qf = (uint32_t)(frame - (int)blockIdx.x * 4);
+    const uint8_t *gpacked = a.packed + (size_t)blockIdx.x * 4 * W * H * MVHP_MB_BYTES;
+    uint8_t *gyuv = a.yuv + (size_t)blockIdx.x * 4 * W * H * 384;
+    uint8_t *grgb = a.rgb + (size_t)blockIdx.x * 4 * W * H * 768;
+    const uint32_t qmb = qf * (uint32_t)(W * H);   // macroblocks in front of this lane's picture (< 2^22): one register;
+                                                   // the three byte offsets are one 24-bit multiply away
+#define OPACKED (__umul24(qmb_v, MVHP_MB_BYTES))
+#define OYUV (__umul24(qmb_v, 384u))
+#define ORGB (__umul24(qmb_v, 768u))
 
     // Packed records are prefetched one macroblock ahead into the registers of the lanes that consume them:
     // every lane of the quarter reads the 32-byte header (same address: one fetch), lane j the 32 bytes of
@@ -200,7 +239,9 @@ __global__ __launch_bounds__(NW * 64) void recon_quad_kernel(ReconArgs a)
     // The loads and the plane stores are inline assembly so that the number of vector-memory operations
     // between a prefetch and its use is fixed: a step issues exactly 0, VM_PAIR or VM_QUAD stores after the twelve loads
     // (`n_st`), and the use is guarded by s_waitcnt vmcnt(n_st) -- the loads have landed, the stores of the step are still in flight.  (Left to the compiler, the wait became vmcnt(0) plus an immediate wait on the header.)
-    // Each asm store carries two wait states: a VALU write of the data registers of a >64-bit store right behind it
+    // Every asm load / store is preceded by five wait states: its scalar base may have been reloaded from a spill lane
+    // (v_readlane, a VALU write of an SGPR) by the instruction right in front of it, and a vector-memory read of such
+    // an SGPR needs that distance.  Each asm store also carries two wait states behind it: a VALU write of the data registers of a >64-bit store right behind it
     // is a hardware hazard the compiler cannot see through inline assembly.
     constexpr int VM_PAIR = RGB ? 8 : 2;      // a macroblock pair: 2 luma (+ 6 RGB) 16-byte stores per lane
     constexpr int VM_QUAD = VM_PAIR + 2;      // ... plus the 32-byte chroma rows of four macroblocks
@@ -209,26 +250,29 @@ __global__ __launch_bounds__(NW * 64) void recon_quad_kernel(ReconArgs a)
     for (int i = 0; i < 12; i++) pf[i] = v2i{0, 0};
     auto prefetch = [&](int prow, int px, int lane_p) {
         const int jj = lane_p & 15;
-        const uint8_t *rec = fpacked + (size_t)(prow * W + px) * MVHP_MB_BYTES;
-        const uint8_t *recL = rec + MVHP_MB_HEADER_BYTES + jj * 32;
-        const uint8_t *recC = rec + MVHP_MB_HEADER_BYTES + ((jj < 8) ? (16 + jj) : jj) * 32;
+        uint32_t qmb_v = qmb;
+        asm volatile("" : "+v"(qmb_v));   // recomputed per use: not worth three registers across the loop
+        const uint32_t rec = OPACKED + (uint32_t)(prow * W + px) * MVHP_MB_BYTES;
+        const uint32_t recL = rec + MVHP_MB_HEADER_BYTES + jj * 32;
+        const uint32_t recC = rec + MVHP_MB_HEADER_BYTES + ((jj < 8) ? (16 + jj) : jj) * 32;
         // 8-byte pieces: a v2i is the widest type whose halves the register-move asm below can name
-        asm volatile("global_load_dwordx2 %0, %1, off" : "=&v"(pf[0]) : "v"(rec) : "memory");
-        asm volatile("global_load_dwordx2 %0, %1, off offset:8" : "=&v"(pf[1]) : "v"(rec) : "memory");
-        asm volatile("global_load_dwordx2 %0, %1, off offset:16" : "=&v"(pf[2]) : "v"(rec) : "memory");
-        asm volatile("global_load_dwordx2 %0, %1, off offset:24" : "=&v"(pf[3]) : "v"(rec) : "memory");
-        asm volatile("global_load_dwordx2 %0, %1, off" : "=&v"(pf[4]) : "v"(recL) : "memory");
-        asm volatile("global_load_dwordx2 %0, %1, off offset:8" : "=&v"(pf[5]) : "v"(recL) : "memory");
-        asm volatile("global_load_dwordx2 %0, %1, off offset:16" : "=&v"(pf[6]) : "v"(recL) : "memory");
-        asm volatile("global_load_dwordx2 %0, %1, off offset:24" : "=&v"(pf[7]) : "v"(recL) : "memory");
-        asm volatile("global_load_dwordx2 %0, %1, off" : "=&v"(pf[8]) : "v"(recC) : "memory");
-        asm volatile("global_load_dwordx2 %0, %1, off offset:8" : "=&v"(pf[9]) : "v"(recC) : "memory");
-        asm volatile("global_load_dwordx2 %0, %1, off offset:16" : "=&v"(pf[10]) : "v"(recC) : "memory");
-        asm volatile("global_load_dwordx2 %0, %1, off offset:24" : "=&v"(pf[11]) : "v"(recC) : "memory");
+        asm volatile("s_nop 4\n\tglobal_load_dwordx2 %0, %1, %2" : "=&v"(pf[0]) : "v"(rec), "s"(gpacked) : "memory");
+        asm volatile("s_nop 4\n\tglobal_load_dwordx2 %0, %1, %2 offset:8" : "=&v"(pf[1]) : "v"(rec), "s"(gpacked) : "memory");
+        asm volatile("s_nop 4\n\tglobal_load_dwordx2 %0, %1, %2 offset:16" : "=&v"(pf[2]) : "v"(rec), "s"(gpacked) : "memory");
+        asm volatile("s_nop 4\n\tglobal_load_dwordx2 %0, %1, %2 offset:24" : "=&v"(pf[3]) : "v"(rec), "s"(gpacked) : "memory");
+        asm volatile("s_nop 4\n\tglobal_load_dwordx2 %0, %1, %2" : "=&v"(pf[4]) : "v"(recL), "s"(gpacked) : "memory");
+        asm volatile("s_nop 4\n\tglobal_load_dwordx2 %0, %1, %2 offset:8" : "=&v"(pf[5]) : "v"(recL), "s"(gpacked) : "memory");
+        asm volatile("s_nop 4\n\tglobal_load_dwordx2 %0, %1, %2 offset:16" : "=&v"(pf[6]) : "v"(recL), "s"(gpacked) : "memory");
+        asm volatile("s_nop 4\n\tglobal_load_dwordx2 %0, %1, %2 offset:24" : "=&v"(pf[7]) : "v"(recL), "s"(gpacked) : "memory");
+        asm volatile("s_nop 4\n\tglobal_load_dwordx2 %0, %1, %2" : "=&v"(pf[8]) : "v"(recC), "s"(gpacked) : "memory");
+        asm volatile("s_nop 4\n\tglobal_load_dwordx2 %0, %1, %2 offset:8" : "=&v"(pf[9]) : "v"(recC), "s"(gpacked) : "memory");
+        asm volatile("s_nop 4\n\tglobal_load_dwordx2 %0, %1, %2 offset:16" : "=&v"(pf[10]) : "v"(recC), "s"(gpacked) : "memory");
+        asm volatile("s_nop 4\n\tglobal_load_dwordx2 %0, %1, %2 offset:24" : "=&v"(pf[11]) : "v"(recC), "s"(gpacked) : "memory");
     };
     if (wave < H) prefetch(wave, 0, lane_c);
     asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
 
+    const int up_adj = __builtin_amdgcn_readfirstlane((wave == 0) ? -1 : 0); // wave 0 follows the last wave's previous pass
     int done = 0; // macroblocks completed by this wave
     int n_st = 0;  // asm stores the previous step issued after its prefetch (0 also when the compiler counted them)
     // Output strips, in registers: 32 bytes is the granularity of HBM writes, so luma (16 B per macroblock row) and
@@ -238,7 +282,8 @@ __global__ __launch_bounds__(NW * 64) void recon_quad_kernel(ReconArgs a)
     uint2 st_cb = make_uint2(0u, 0u), st_cr = st_cb;    // chroma rows (j >> 1) of the even macroblock, for its RGB
     for (int row = wave; row < H; row += NW) {
         const int pass = row / NW;
-        const int up_base = ((wave == 0) ? (pass - 1) : pass) * W; // MBs the upper wave finished before its row (row-1)
+        // MBs the upper wave finished before its row (row-1); kept scalar explicitly
+        const int up_base = (pass + up_adj) * W;
         const bool Bv = row > 0;
 #pragma unroll 1
         for (int mbx = 0; mbx < W; mbx++) {
@@ -384,12 +429,22 @@ __global__ __launch_bounds__(NW * 64) void recon_quad_kernel(ReconArgs a)
                         if (qpy > 36) dc = (int)((unsigned)(f * lsA) << ((s - 6) & 31));
                         else dc = (int)((unsigned)(f * lsA) + (1u << ((5 - s) & 31))) >> ((6 - s) & 31);
                     }
-                    // quant4x4, h264_transform.c:1100-1134: ((c*LS + rnd) >> shr) << shl, the left shift folded into LS
+                    // quant4x4, h264_transform.c:1100-1134: ((c*LS + rnd) >> shr) << shl, the left shift folded into LS;
+                    // shr = rnd = 0 from qP 24 up (checked for the whole wave)
+                    if (__builtin_amdgcn_ballot_w64(shr != 0) == 0) {
 #pragma unroll
-                    for (int i = 0; i < 16; i++) {
-                        const int r = i >> 2, c = i & 3;
-                        const int ls = ((r & 1) == 0 && (c & 1) == 0) ? qt.x : (((r & 1) && (c & 1)) ? qt.y : qt.z);
-                        d[i] = (__mul24(d[i], ls) + rnd) >> shr;
+                        for (int i = 0; i < 16; i++) {
+                            const int r = i >> 2, c = i & 3;
+                            const int ls = ((r & 1) == 0 && (c & 1) == 0) ? qt.x : (((r & 1) && (c & 1)) ? qt.y : qt.z);
+                            d[i] = __mul24(d[i], ls);
+                        }
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 16; i++) {
+                            const int r = i >> 2, c = i & 3;
+                            const int ls = ((r & 1) == 0 && (c & 1) == 0) ? qt.x : (((r & 1) && (c & 1)) ? qt.y : qt.z);
+                            d[i] = (__mul24(d[i], ls) + rnd) >> shr;
+                        }
                     }
                     if (kind == MVHP_KIND_I16x16) d[0] = dc;
                     d[0] += 32;
@@ -420,11 +475,20 @@ __global__ __launch_bounds__(NW * 64) void recon_quad_kernel(ReconArgs a)
                 const int f = (k == 0) ? (c0 + c1 + c2v + c3) : (k == 1) ? (c0 - c1 + c2v - c3)
                             : (k == 2) ? (c0 + c1 - c2v - c3) : (c0 - c1 - c2v + c3);
                 const int dc = (int)((unsigned)(f * B.ls0[qpc]) << s) >> 5;
+                if (__builtin_amdgcn_ballot_w64(shr != 0) == 0) {
 #pragma unroll
-                for (int i = 0; i < 16; i++) {
-                    const int r = i >> 2, c = i & 3;
-                    const int ls = ((r & 1) == 0 && (c & 1) == 0) ? qt.x : (((r & 1) && (c & 1)) ? qt.y : qt.z);
-                    d[i] = (__mul24(d[i], ls) + rnd) >> shr;
+                    for (int i = 1; i < 16; i++) {
+                        const int r = i >> 2, c = i & 3;
+                        const int ls = ((r & 1) == 0 && (c & 1) == 0) ? qt.x : (((r & 1) && (c & 1)) ? qt.y : qt.z);
+                        d[i] = __mul24(d[i], ls);
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 1; i < 16; i++) {
+                        const int r = i >> 2, c = i & 3;
+                        const int ls = ((r & 1) == 0 && (c & 1) == 0) ? qt.x : (((r & 1) && (c & 1)) ? qt.y : qt.z);
+                        d[i] = (__mul24(d[i], ls) + rnd) >> shr;
+                    }
                 }
                 d[0] = dc + 32;
                 idct4x4(d);
@@ -460,6 +524,56 @@ __global__ __launch_bounds__(NW * 64) void recon_quad_kernel(ReconArgs a)
             WAVE_SYNC();
 
             // =====================================================================================
+            // chroma prediction (h264_intra_prediction.c:2157-2564 + transform4x4_chroma): lane j < 8 predicts
+            // its own 4x4 block (plane j >> 2, block j & 3)
+            // =====================================================================================
+            if (j < 8) {
+                const int pl = j >> 2, k = j & 3;
+                const int cx = (k & 1) * 4, cy = (k >> 1) * 4;
+                uint8_t *TCp = Q.TC[pl];
+                uint32_t pw[4] = {0u, 0u, 0u, 0u};
+                const uint32_t topw = *reinterpret_cast<const uint32_t *>(&TCp[8 + cx]);
+                const uint32_t lefw = *reinterpret_cast<const uint32_t *>(&Q.LcolC[pl][cy]);
+                if (cmode == 0) {
+                    const int bx = k & 1, by = k >> 1;
+                    const int sH = sum4(topw), sV = sum4(lefw);
+                    int v;
+                    if (!A && !Bv) v = 128;
+                    else if (bx == by) {
+                        if (A && Bv) v = (sH + sV + 4) >> 3;
+                        else if (A) v = (sV + 2) >> 2;
+                        else v = (sH + 2) >> 2;
+                    } else if (bx == 1) { // xO > 0, yO == 0: prefers top
+                        v = Bv ? ((sH + 2) >> 2) : ((sV + 2) >> 2);
+                    } else {              // xO == 0, yO > 0: prefers left
+                        v = A ? ((sV + 2) >> 2) : ((sH + 2) >> 2);
+                    }
+                    pw[0] = pw[1] = pw[2] = pw[3] = (uint32_t)v * 0x01010101u;
+                } else if (cmode == 1) {
+                    if (A) {
+#pragma unroll
+                        for (int y = 0; y < 4; y++) pw[y] = ((lefw >> (8 * y)) & 255u) * 0x01010101u;
+                    }
+                } else if (cmode == 2) {
+                    if (Bv) pw[0] = pw[1] = pw[2] = pw[3] = topw;
+                } else if (cmode == 3) {
+                    if (A && Bv) {
+                        const uint2 topv = *reinterpret_cast<const uint2 *>(&TCp[8]);
+                        const uint2 lefv = *reinterpret_cast<const uint2 *>(Q.LcolC[pl]);
+                        const int cor = TCp[7];
+                        const int Hh = plane_grad8(topv, (uint32_t)cor), Vv = plane_grad8(lefv, (uint32_t)cor);
+                        const int aa = 16 * ((int)(lefv.y >> 24) + (int)(topv.y >> 24));
+                        const int bb = (34 * Hh + 32) >> 6;
+                        const int cc = (34 * Vv + 32) >> 6;
+                        const int v00 = aa + bb * (cx - 3) + cc * (cy - 3) + 16;
+#pragma unroll
+                        for (int y = 0; y < 4; y++) pw[y] = plane_row(v00 + cc * y, bb);
+                    }
+                }
+                emit_block(&TCp[(cy + 1) * 16 + 8 + cx], 16, pw, c2);
+            }
+
+            // =====================================================================================
             // luma prediction
             // =====================================================================================
             if (kind == MVHP_KIND_I16x16) {
@@ -489,19 +603,7 @@ __global__ __launch_bounds__(NW * 64) void recon_quad_kernel(ReconArgs a)
                         const uint4 topv = *reinterpret_cast<const uint4 *>(&Q.T[16]);
                         const uint4 lefv = *reinterpret_cast<const uint4 *>(Q.Lcol);
                         const int cor = Q.T[15];
-                        const uint32_t tw[4] = {topv.x, topv.y, topv.z, topv.w};
-                        const uint32_t lw[4] = {lefv.x, lefv.y, lefv.z, lefv.w};
-                        int Hh = 0, Vv = 0;
-#pragma unroll
-                        for (int i = 0; i < 8; i++) {
-                            const int hi = 8 + i, lo = 6 - i;
-                            const int th = (tw[hi >> 2] >> ((hi & 3) * 8)) & 255;
-                            const int lh = (lw[hi >> 2] >> ((hi & 3) * 8)) & 255;
-                            const int tl = (lo < 0) ? cor : (int)((tw[lo >> 2] >> ((lo & 3) * 8)) & 255);
-                            const int ll = (lo < 0) ? cor : (int)((lw[lo >> 2] >> ((lo & 3) * 8)) & 255);
-                            Hh += (i + 1) * (th - tl);
-                            Vv += (i + 1) * (lh - ll);
-                        }
+                        const int Hh = plane_grad16(topv, (uint32_t)cor), Vv = plane_grad16(lefv, (uint32_t)cor);
                         const int aa = 16 * ((int)(lefv.w >> 24) + (int)(topv.w >> 24));
                         const int bb = (5 * Hh + 32) >> 6;
                         const int cc = (5 * Vv + 32) >> 6;
@@ -656,66 +758,6 @@ __global__ __launch_bounds__(NW * 64) void recon_quad_kernel(ReconArgs a)
                 }
             }
 
-            // =====================================================================================
-            // chroma prediction (h264_intra_prediction.c:2157-2564 + transform4x4_chroma): lane j < 8 predicts
-            // its own 4x4 block (plane j >> 2, block j & 3)
-            // =====================================================================================
-            if (j < 8) {
-                const int pl = j >> 2, k = j & 3;
-                const int cx = (k & 1) * 4, cy = (k >> 1) * 4;
-                uint8_t *TCp = Q.TC[pl];
-                uint32_t pw[4] = {0u, 0u, 0u, 0u};
-                const uint32_t topw = *reinterpret_cast<const uint32_t *>(&TCp[8 + cx]);
-                const uint32_t lefw = *reinterpret_cast<const uint32_t *>(&Q.LcolC[pl][cy]);
-                if (cmode == 0) {
-                    const int bx = k & 1, by = k >> 1;
-                    const int sH = sum4(topw), sV = sum4(lefw);
-                    int v;
-                    if (!A && !Bv) v = 128;
-                    else if (bx == by) {
-                        if (A && Bv) v = (sH + sV + 4) >> 3;
-                        else if (A) v = (sV + 2) >> 2;
-                        else v = (sH + 2) >> 2;
-                    } else if (bx == 1) { // xO > 0, yO == 0: prefers top
-                        v = Bv ? ((sH + 2) >> 2) : ((sV + 2) >> 2);
-                    } else {              // xO == 0, yO > 0: prefers left
-                        v = A ? ((sV + 2) >> 2) : ((sH + 2) >> 2);
-                    }
-                    pw[0] = pw[1] = pw[2] = pw[3] = (uint32_t)v * 0x01010101u;
-                } else if (cmode == 1) {
-                    if (A) {
-#pragma unroll
-                        for (int y = 0; y < 4; y++) pw[y] = ((lefw >> (8 * y)) & 255u) * 0x01010101u;
-                    }
-                } else if (cmode == 2) {
-                    if (Bv) pw[0] = pw[1] = pw[2] = pw[3] = topw;
-                } else if (cmode == 3) {
-                    if (A && Bv) {
-                        const uint2 topv = *reinterpret_cast<const uint2 *>(&TCp[8]);
-                        const uint2 lefv = *reinterpret_cast<const uint2 *>(Q.LcolC[pl]);
-                        const int cor = TCp[7];
-                        const uint32_t tw[2] = {topv.x, topv.y}, lw[2] = {lefv.x, lefv.y};
-                        int Hh = 0, Vv = 0;
-#pragma unroll
-                        for (int i = 0; i < 4; i++) {
-                            const int hi = 4 + i, lo = 2 - i;
-                            const int th = (tw[hi >> 2] >> ((hi & 3) * 8)) & 255;
-                            const int lh = (lw[hi >> 2] >> ((hi & 3) * 8)) & 255;
-                            const int tl = (lo < 0) ? cor : (int)((tw[0] >> (lo * 8)) & 255);
-                            const int ll = (lo < 0) ? cor : (int)((lw[0] >> (lo * 8)) & 255);
-                            Hh += (i + 1) * (th - tl);
-                            Vv += (i + 1) * (lh - ll);
-                        }
-                        const int aa = 16 * ((int)(lefv.y >> 24) + (int)(topv.y >> 24));
-                        const int bb = (34 * Hh + 32) >> 6;
-                        const int cc = (34 * Vv + 32) >> 6;
-                        const int v00 = aa + bb * (cx - 3) + cc * (cy - 3) + 16;
-#pragma unroll
-                        for (int y = 0; y < 4; y++) pw[y] = plane_row(v00 + cc * y, bb);
-                    }
-                }
-                emit_block(&TCp[(cy + 1) * 16 + 8 + cx], 16, pw, c2);
-            }
             WAVE_SYNC();
 
             // =====================================================================================
@@ -735,30 +777,34 @@ __global__ __launch_bounds__(NW * 64) void recon_quad_kernel(ReconArgs a)
                 }
                 const v4i yq = {(int)yv.x, (int)yv.y, (int)yv.z, (int)yv.w};
                 const v2i cq = {(int)cv.x, (int)cv.y};
-                uint8_t *py = &fy[(size_t)(row * 16 + j) * pitch + (mbx & ~1) * 16];
-                uint8_t *pc = fy + plane_y + (size_t)(j >> 3) * plane_c + (size_t)(row * 8 + (j & 7)) * cpitch + (mbx & ~3) * 8;
-                uint8_t *prgb = RGB ? frgb + ((size_t)(row * 16 + j) * pitch + (mbx & ~1) * 16) * 3 : nullptr;
+                const uint32_t lrow = (uint32_t)((row * 16 + j) * pitch + (mbx & ~1) * 16);   // inside the luma plane
+                uint32_t qmb_v = qmb;
+                asm volatile("" : "+v"(qmb_v));
+                const uint32_t oyuv = OYUV;
+                const uint32_t py = oyuv + lrow;
+                const uint32_t pc = oyuv + plane_y + (uint32_t)(j >> 3) * plane_c + (uint32_t)((row * 8 + (j & 7)) * cpitch + (mbx & ~3) * 8);
+                const uint32_t prgb = ORGB + lrow * 3u;
                 n_st = 0;
                 if (mbx & 1) {
                     // ---- pair flush: exactly VM_PAIR store instructions ----
                     if (valid) {
-                        asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" : : "v"(py), "v"(st_y) : "memory");
-                        asm volatile("global_store_dwordx4 %0, %1, off offset:16\n\ts_nop 1" : : "v"(py), "v"(yq) : "memory");
+                        asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2\n\ts_nop 1" : : "v"(py), "v"(st_y), "s"(gyuv) : "memory");
+                        asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 offset:16\n\ts_nop 1" : : "v"(py), "v"(yq), "s"(gyuv) : "memory");
                     }
                     if (RGB) {
                         v4i a0, a1, a2;
                         const uint4 y0 = make_uint4((uint32_t)st_y.x, (uint32_t)st_y.y, (uint32_t)st_y.z, (uint32_t)st_y.w);
                         rgb16(y0, st_cb, st_cr, a0, a1, a2);
                         if (valid) {
-                            asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" : : "v"(prgb), "v"(a0) : "memory");
-                            asm volatile("global_store_dwordx4 %0, %1, off offset:16\n\ts_nop 1" : : "v"(prgb), "v"(a1) : "memory");
-                            asm volatile("global_store_dwordx4 %0, %1, off offset:32\n\ts_nop 1" : : "v"(prgb), "v"(a2) : "memory");
+                            asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2\n\ts_nop 1" : : "v"(prgb), "v"(a0), "s"(grgb) : "memory");
+                            asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 offset:16\n\ts_nop 1" : : "v"(prgb), "v"(a1), "s"(grgb) : "memory");
+                            asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 offset:32\n\ts_nop 1" : : "v"(prgb), "v"(a2), "s"(grgb) : "memory");
                         }
                         rgb16(yv, cbv, crv, a0, a1, a2);
                         if (valid) {
-                            asm volatile("global_store_dwordx4 %0, %1, off offset:48\n\ts_nop 1" : : "v"(prgb), "v"(a0) : "memory");
-                            asm volatile("global_store_dwordx4 %0, %1, off offset:64\n\ts_nop 1" : : "v"(prgb), "v"(a1) : "memory");
-                            asm volatile("global_store_dwordx4 %0, %1, off offset:80\n\ts_nop 1" : : "v"(prgb), "v"(a2) : "memory");
+                            asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 offset:48\n\ts_nop 1" : : "v"(prgb), "v"(a0), "s"(grgb) : "memory");
+                            asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 offset:64\n\ts_nop 1" : : "v"(prgb), "v"(a1), "s"(grgb) : "memory");
+                            asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 offset:80\n\ts_nop 1" : : "v"(prgb), "v"(a2), "s"(grgb) : "memory");
                         }
                     }
                     n_st = VM_PAIR;
@@ -766,16 +812,16 @@ __global__ __launch_bounds__(NW * 64) void recon_quad_kernel(ReconArgs a)
                         // ---- chroma of four macroblocks: exactly two more store instructions ----
                         const v4i c01 = {st_c0.x, st_c0.y, st_c1.x, st_c1.y}, c23 = {st_c2.x, st_c2.y, cq.x, cq.y};
                         if (valid) {
-                            asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" : : "v"(pc), "v"(c01) : "memory");
-                            asm volatile("global_store_dwordx4 %0, %1, off offset:16\n\ts_nop 1" : : "v"(pc), "v"(c23) : "memory");
+                            asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2\n\ts_nop 1" : : "v"(pc), "v"(c01), "s"(gyuv) : "memory");
+                            asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 offset:16\n\ts_nop 1" : : "v"(pc), "v"(c23), "s"(gyuv) : "memory");
                         }
                         n_st = VM_QUAD;
                     } else {
                         st_c1 = cq;
                         if (mbx == W - 1) { // W % 4 == 2: two macroblocks of chroma left (compiler-counted stores)
                             if (valid) {
-                                *reinterpret_cast<v2i *>(pc) = st_c0;
-                                *reinterpret_cast<v2i *>(pc + 8) = st_c1;
+                                *reinterpret_cast<v2i *>(gyuv + pc) = st_c0;
+                                *reinterpret_cast<v2i *>(gyuv + pc + 8) = st_c1;
                             }
                             n_st = 0;
                         }
@@ -783,19 +829,19 @@ __global__ __launch_bounds__(NW * 64) void recon_quad_kernel(ReconArgs a)
                 } else if (mbx == W - 1) {
                     // ---- odd picture width: the last macroblock leaves alone (compiler-counted stores) ----
                     if (valid) {
-                        *reinterpret_cast<v4i *>(py) = yq;
-                        if (mbi == 0) *reinterpret_cast<v2i *>(pc) = cq;
+                        *reinterpret_cast<v4i *>(gyuv + py) = yq;
+                        if (mbi == 0) *reinterpret_cast<v2i *>(gyuv + pc) = cq;
                         else { // mbi == 2
-                            *reinterpret_cast<v2i *>(pc) = st_c0;
-                            *reinterpret_cast<v2i *>(pc + 8) = st_c1;
-                            *reinterpret_cast<v2i *>(pc + 16) = cq;
+                            *reinterpret_cast<v2i *>(gyuv + pc) = st_c0;
+                            *reinterpret_cast<v2i *>(gyuv + pc + 8) = st_c1;
+                            *reinterpret_cast<v2i *>(gyuv + pc + 16) = cq;
                         }
                     }
                     if (RGB) {
                         v4i a0, a1, a2;
                         rgb16(yv, cbv, crv, a0, a1, a2);
                         if (valid) {
-                            v4i *dst = reinterpret_cast<v4i *>(prgb);
+                            v4i *dst = reinterpret_cast<v4i *>(grgb + prgb);
                             dst[0] = a0; dst[1] = a1; dst[2] = a2;
                         }
                     }
@@ -843,6 +889,10 @@ __global__ __launch_bounds__(NW * 64) void recon_quad_kernel(ReconArgs a)
         }
     }
 }
+
+#undef OPACKED
+#undef OYUV
+#undef ORGB
 
 size_t recon_quad_lds_bytes(int width_mbs, int nw)
 {

@@ -60,6 +60,9 @@ def check(L, name):
             continue
         if regs(l) & dest:
             bad.append((i, l))
+    # register spills (scratch_*) are vector-memory operations too: none may sit inside the macroblock loop
+    spills = [i for i in range(labi, max(back) + 1) if re.match(r'\s+scratch_', L[i])]
+    assert not spills, (name, 'scratch access inside the macroblock loop', spills[:3])
     # the two wait blocks themselves read the prefetch registers (that is their job); nothing else may
     bad = [(i, l) for i, l in bad if not any(w < i <= w + 12 for w in waits)]
     assert not bad, (name, bad[:5])
