@@ -35,8 +35,8 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--frames", type=int, default=1536, help="pictures per GPU per step (two full rounds of the "
-                    "768 picture-workgroups an MI355X holds at 3 x 8 waves per CU)")
+    ap.add_argument("--frames", type=int, default=2048, help="pictures per GPU per step (512 four-picture workgroups = "
+                    "two 8-wave workgroups on each of the 256 CUs)")
     ap.add_argument("--distinct", type=int, default=16, help="distinct synthetic pictures tiled to --frames")
     ap.add_argument("--width-mbs", type=int, default=120)
     ap.add_argument("--height-mbs", type=int, default=68)
@@ -60,7 +60,7 @@ def measured_traffic(args, fused, kernel):
     (tools/pmc_profile.sh: FETCH_SIZE and WRITE_SIZE in separate passes; FETCH_SIZE doubled per the gfx950
     correction in MI355X_MICROARCH.md).  Only reported when the run uses the profiled configuration."""
     path = os.path.join(ROOT, "profiles", "r01_v4_pmc_summary.json")
-    default = (args.frames == 1536 and args.width_mbs == 120 and args.height_mbs == 68 and args.profile == "baseline"
+    default = (args.frames == 2048 and args.width_mbs == 120 and args.height_mbs == 68 and args.profile == "baseline"
                and args.density == "dense" and args.source == "stream" and fused and not args.waves)
     if not (default and os.path.exists(path)):
         return None, None

@@ -185,9 +185,9 @@ static int pick_waves(const mvhp_ctx *c, const mvhp_stream_params_t *p, int n_fr
     int nw = c->waves;
     if (quad) {
         // speed only: the quad kernel is built for 4, 6, 8 and 12 waves (at 16 its register budget would force
-        // spills); 6-wave workgroups fit two to a CU = 12 waves per CU, the most its registers allow
+        // spills); 8-wave workgroups fit two to a CU (LDS, 128 VGPRs) = 16 waves per CU
         static const int opts[4] = {12, 8, 6, 4};
-        if (nw == 0) nw = 6;
+        if (nw == 0) nw = 8;
         for (int k = 0; k < 4; k++) {
             const int o = opts[k];
             if (o > nw) continue;

@@ -40,9 +40,9 @@ struct __attribute__((aligned(16))) QLds {
     uint8_t Lcol[16];        // compact left neighbour column (luma)
     uint8_t LcolC[2][8];     // compact left neighbour columns (Cb, Cr)
     uint8_t E8[32];          // filtered Intra8x8 edge, see recon_device.h mode_entry()
-    uint8_t pad[16];         // 1440 B: quarters land 360 dwords apart (different banks)
-};
-static_assert(sizeof(QLds) == 1440, "QLds layout");
+    uint8_t SC[2][8 * 24];   // output strip, chroma: rows of the three parked macroblocks (the fourth flushes from registers)
+};                           // 1808 B: quarters land 452 dwords apart (different banks)
+static_assert(sizeof(QLds) == 1808, "QLds layout");
 
 struct __attribute__((aligned(16))) QTables {
     int      progress[16];   // macroblocks completed by wave w (monotonic over its rows)
@@ -180,8 +180,12 @@ __device__ __forceinline__ int had4_lanes(int x, int p, int idx, int addrP, int 
 }
 
 // 128 VGPRs = four waves per SIMD: two 8-wave workgroups (or four 4-wave ones) per CU; LDS allows as many.
+// The compiler gets v0-v99 (plus one register above everything for its SGPR spill lanes); v100-v123 are the
+// record prefetch registers, named only inside inline assembly, so
+// that nothing the compiler generates (copies, spills, reuse as temporaries) can touch a register a load is
+// still writing.
 template <int NW, bool RGB>
-__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW == 12 ? 3 : 4, NW == 12 ? 3 : 4))) void recon_quad_kernel(ReconArgs a)
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_num_vgpr(100))) void recon_quad_kernel(ReconArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int W = a.width_mbs, H = a.height_mbs;
@@ -237,17 +241,17 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW == 1
     // every lane of the quarter reads the 32-byte header (same address: one fetch), lane j the 32 bytes of
     // luma block j and, for j < 8, the 32 bytes of chroma block j (lanes 8-15 repeat their luma address).
     // The loads and the plane stores are inline assembly so that the number of vector-memory operations
-    // between a prefetch and its use is fixed: a step issues exactly 0, VM_PAIR or VM_QUAD stores after the twelve loads
-    // (`n_st`), and the use is guarded by s_waitcnt vmcnt(n_st) -- the loads have landed, the stores of the step are still in flight.  (Left to the compiler, the wait became vmcnt(0) plus an immediate wait on the header.)
+    // between a prefetch and its use is fixed: a step issues either no store or exactly VM_STRIP stores after the twelve
+    // loads (`n_st`), and the use is guarded by s_waitcnt vmcnt(n_st) -- the loads have landed, the stores of the step are still in flight.  (Left to the compiler, the wait became vmcnt(0) plus an immediate wait on the header.)
     // Every asm load / store is preceded by five wait states: its scalar base may have been reloaded from a spill lane
     // (v_readlane, a VALU write of an SGPR) by the instruction right in front of it, and a vector-memory read of such
     // an SGPR needs that distance.  Each asm store also carries two wait states behind it: a VALU write of the data registers of a >64-bit store right behind it
     // is a hardware hazard the compiler cannot see through inline assembly.
-    constexpr int VM_PAIR = RGB ? 8 : 2;      // a macroblock pair: 2 luma (+ 6 RGB) 16-byte stores per lane
-    constexpr int VM_QUAD = VM_PAIR + 2;      // ... plus the 32-byte chroma rows of four macroblocks
-    v2i pf[12];
-#pragma unroll
-    for (int i = 0; i < 12; i++) pf[i] = v2i{0, 0};
+#if defined(MVHP_ABL_NO_RGB_STORE)
+    constexpr int VM_STRIP = 6;               // measurement build: RGB computed, not stored
+#else
+    constexpr int VM_STRIP = RGB ? 18 : 6;    // a full strip: 4 luma + 2 chroma (+ 12 RGB) 16-byte stores per lane
+#endif
     auto prefetch = [&](int prow, int px, int lane_p) {
         const int jj = lane_p & 15;
         uint32_t qmb_v = qmb;
@@ -255,31 +259,29 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW == 1
         const uint32_t rec = OPACKED + (uint32_t)(prow * W + px) * MVHP_MB_BYTES;
         const uint32_t recL = rec + MVHP_MB_HEADER_BYTES + jj * 32;
         const uint32_t recC = rec + MVHP_MB_HEADER_BYTES + ((jj < 8) ? (16 + jj) : jj) * 32;
-        // 8-byte pieces: a v2i is the widest type whose halves the register-move asm below can name
-        asm volatile("s_nop 4\n\tglobal_load_dwordx2 %0, %1, %2" : "=&v"(pf[0]) : "v"(rec), "s"(gpacked) : "memory");
-        asm volatile("s_nop 4\n\tglobal_load_dwordx2 %0, %1, %2 offset:8" : "=&v"(pf[1]) : "v"(rec), "s"(gpacked) : "memory");
-        asm volatile("s_nop 4\n\tglobal_load_dwordx2 %0, %1, %2 offset:16" : "=&v"(pf[2]) : "v"(rec), "s"(gpacked) : "memory");
-        asm volatile("s_nop 4\n\tglobal_load_dwordx2 %0, %1, %2 offset:24" : "=&v"(pf[3]) : "v"(rec), "s"(gpacked) : "memory");
-        asm volatile("s_nop 4\n\tglobal_load_dwordx2 %0, %1, %2" : "=&v"(pf[4]) : "v"(recL), "s"(gpacked) : "memory");
-        asm volatile("s_nop 4\n\tglobal_load_dwordx2 %0, %1, %2 offset:8" : "=&v"(pf[5]) : "v"(recL), "s"(gpacked) : "memory");
-        asm volatile("s_nop 4\n\tglobal_load_dwordx2 %0, %1, %2 offset:16" : "=&v"(pf[6]) : "v"(recL), "s"(gpacked) : "memory");
-        asm volatile("s_nop 4\n\tglobal_load_dwordx2 %0, %1, %2 offset:24" : "=&v"(pf[7]) : "v"(recL), "s"(gpacked) : "memory");
-        asm volatile("s_nop 4\n\tglobal_load_dwordx2 %0, %1, %2" : "=&v"(pf[8]) : "v"(recC), "s"(gpacked) : "memory");
-        asm volatile("s_nop 4\n\tglobal_load_dwordx2 %0, %1, %2 offset:8" : "=&v"(pf[9]) : "v"(recC), "s"(gpacked) : "memory");
-        asm volatile("s_nop 4\n\tglobal_load_dwordx2 %0, %1, %2 offset:16" : "=&v"(pf[10]) : "v"(recC), "s"(gpacked) : "memory");
-        asm volatile("s_nop 4\n\tglobal_load_dwordx2 %0, %1, %2 offset:24" : "=&v"(pf[11]) : "v"(recC), "s"(gpacked) : "memory");
+        asm volatile("s_nop 4\n\t"
+                     "global_load_dwordx4 v[100:103], %0, %3\n\t"
+                     "global_load_dwordx4 v[104:107], %0, %3 offset:16\n\t"
+                     "global_load_dwordx4 v[108:111], %1, %3\n\t"
+                     "global_load_dwordx4 v[112:115], %1, %3 offset:16\n\t"
+                     "global_load_dwordx4 v[116:119], %2, %3\n\t"
+                     "global_load_dwordx4 v[120:123], %2, %3 offset:16"
+                     : : "v"(rec), "v"(recL), "v"(recC), "s"(gpacked)
+                     : "memory", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111",
+                       "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123");
     };
     if (wave < H) prefetch(wave, 0, lane_c);
-    asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
+    asm volatile("s_waitcnt vmcnt(0)" : : : "memory");   // (a wave without rows never reads the registers)
 
     const int up_adj = __builtin_amdgcn_readfirstlane((wave == 0) ? -1 : 0); // wave 0 follows the last wave's previous pass
     int done = 0; // macroblocks completed by this wave
     int n_st = 0;  // asm stores the previous step issued after its prefetch (0 also when the compiler counted them)
-    // Output strips, in registers: 32 bytes is the granularity of HBM writes, so luma (16 B per macroblock row) and
-    // RGB (48 B) leave in pairs of macroblocks and chroma (8 B) in fours.
-    v4i st_y = {0, 0, 0, 0};                       // luma row j of the even macroblock of the pair
-    v2i st_c0 = {0, 0}, st_c1 = st_c0, st_c2 = st_c0;   // chroma row (j & 7) of plane (j >> 3), macroblocks 0..2 of the four
-    uint2 st_cb = make_uint2(0u, 0u), st_cr = st_cb;    // chroma rows (j >> 1) of the even macroblock, for its RGB
+    // Output strip: lane j parks luma row j (16 B, registers) and chroma row j & 7 of plane j >> 3 (8 B, LDS) of three
+    // macroblocks; the fourth one triggers the flush:
+    // 64 bytes of luma, 32 of chroma and 192 of RGB per lane, contiguous (HBM likes long runs: with 16-byte runs the
+    // write traffic doubled, with 32-byte runs the writes alone cost 40 % of the kernel).
+    v4i st_y0 = {0, 0, 0, 0}, st_y1 = st_y0, st_y2 = st_y0;
+    // (the parked chroma rows live in LDS, Q.SC: both the lane's own row and the rows the RGB conversion needs)
     for (int row = wave; row < H; row += NW) {
         const int pass = row / NW;
         // MBs the upper wave finished before its row (row-1); kept scalar explicitly
@@ -298,32 +300,25 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW == 1
             uint8_t *line_cr = line_cb + W * 8;
             const bool A = mbx > 0, C = Bv && (mbx < W - 1), D = A && Bv;
 
-            // wait for the prefetched record, then move it out of the prefetch registers -- the moves are part of
-            // the same asm block so that nothing can read those registers before the wait
+            // wait for the prefetched record and move it into compiler-visible registers (one asm block: nothing can
+            // read v100-v123 before the wait); the next prefetch is issued behind the residual stage
             v2i w[12];
-#define MVHP_WAIT_AND_TAKE(N)                                                                                          \
-            asm volatile("s_waitcnt vmcnt(%24)\n\t"                                                                    \
-                         "v_mov_b64 %0, %12\n\tv_mov_b64 %1, %13\n\tv_mov_b64 %2, %14\n\tv_mov_b64 %3, %15\n\t"        \
-                         "v_mov_b64 %4, %16\n\tv_mov_b64 %5, %17\n\tv_mov_b64 %6, %18\n\tv_mov_b64 %7, %19\n\t"        \
-                         "v_mov_b64 %8, %20\n\tv_mov_b64 %9, %21\n\tv_mov_b64 %10, %22\n\tv_mov_b64 %11, %23"           \
+#define MVHP_WAIT_PREFETCH(N)                                                                                          \
+            asm volatile("s_waitcnt vmcnt(%12)\n\t"                                                                    \
+                         "v_mov_b64 %0, v[100:101]\n\tv_mov_b64 %1, v[102:103]\n\tv_mov_b64 %2, v[104:105]\n\t"         \
+                         "v_mov_b64 %3, v[106:107]\n\tv_mov_b64 %4, v[108:109]\n\tv_mov_b64 %5, v[110:111]\n\t"         \
+                         "v_mov_b64 %6, v[112:113]\n\tv_mov_b64 %7, v[114:115]\n\tv_mov_b64 %8, v[116:117]\n\t"         \
+                         "v_mov_b64 %9, v[118:119]\n\tv_mov_b64 %10, v[120:121]\n\tv_mov_b64 %11, v[122:123]"            \
                          : "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2]), "=&v"(w[3]), "=&v"(w[4]), "=&v"(w[5]),                \
                            "=&v"(w[6]), "=&v"(w[7]), "=&v"(w[8]), "=&v"(w[9]), "=&v"(w[10]), "=&v"(w[11])               \
-                         : "v"(pf[0]), "v"(pf[1]), "v"(pf[2]), "v"(pf[3]), "v"(pf[4]), "v"(pf[5]),                      \
-                           "v"(pf[6]), "v"(pf[7]), "v"(pf[8]), "v"(pf[9]), "v"(pf[10]), "v"(pf[11]), "n"(N)             \
+                         : "n"(N)                                                                                      \
                          : "memory")
-            if (n_st == VM_QUAD) MVHP_WAIT_AND_TAKE(VM_QUAD);
-            else if (n_st == VM_PAIR) MVHP_WAIT_AND_TAKE(VM_PAIR);
-            else MVHP_WAIT_AND_TAKE(0);
-#undef MVHP_WAIT_AND_TAKE
+            if (n_st) MVHP_WAIT_PREFETCH(VM_STRIP);
+            else MVHP_WAIT_PREFETCH(0);
+#undef MVHP_WAIT_PREFETCH
             const int4 cH0 = make_int4(w[0].x, w[0].y, w[1].x, w[1].y), cH1 = make_int4(w[2].x, w[2].y, w[3].x, w[3].y);
             const int4 cLA = make_int4(w[4].x, w[4].y, w[5].x, w[5].y), cLB = make_int4(w[6].x, w[6].y, w[7].x, w[7].y);
             const int4 cCA = make_int4(w[8].x, w[8].y, w[9].x, w[9].y), cCB = make_int4(w[10].x, w[10].y, w[11].x, w[11].y);
-            {   // next macroblock of this wave: same row, or the first of its next row (none left: this one again)
-                int nrow = row, nx = mbx + 1;
-                if (nx >= W) { nrow = row + NW; nx = 0; }
-                if (nrow >= H) { nrow = row; nx = mbx; }
-                prefetch(nrow, nx, lane);
-            }
             const uint32_t h0 = (uint32_t)cH0.x, h1 = (uint32_t)cH0.y, nz = (uint32_t)cH0.z;
             const uint32_t m0 = (uint32_t)cH0.w, m1 = (uint32_t)cH1.x, m2 = (uint32_t)cH1.y, m3 = (uint32_t)cH1.z;
             const int kind = h0 & 255;
@@ -494,6 +489,14 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW == 1
                 idct4x4(d);
 #pragma unroll
                 for (int i = 0; i < 8; i++) c2[i] = need_c ? pack_res(d[2 * i], d[2 * i + 1]) : 0;
+            }
+
+            {   // the record is consumed: prefetch the next macroblock of this wave -- same row, or the first of its
+                // next row (none left: this one again)
+                int nrow = row, nx = mbx + 1;
+                if (nx >= W) { nrow = row + NW; nx = 0; }
+                if (nrow >= H) { nrow = row; nx = mbx; }
+                prefetch(nrow, nx, lane);
             }
 
             // =====================================================================================
@@ -761,10 +764,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW == 1
             WAVE_SYNC();
 
             // =====================================================================================
-            // write-out: lane j holds luma row j (16 B) and chroma row j & 7 of plane j >> 3 (8 B) of this
-            // macroblock.  Even macroblocks are parked in registers; odd ones leave with their left neighbour as
-            // 32-byte luma and 96-byte RGB row segments (mb_to_rgb, export_utils.c:209-324, fused), every fourth
-            // one also takes 32 bytes of chroma along.
+            // write-out (mb_to_rgb, export_utils.c:209-324, fused): park, or flush the 4-macroblock strip
             // =====================================================================================
             {
                 const int mbi = mbx & 3;
@@ -777,80 +777,96 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW == 1
                 }
                 const v4i yq = {(int)yv.x, (int)yv.y, (int)yv.z, (int)yv.w};
                 const v2i cq = {(int)cv.x, (int)cv.y};
-                const uint32_t lrow = (uint32_t)((row * 16 + j) * pitch + (mbx & ~1) * 16);   // inside the luma plane
-                uint32_t qmb_v = qmb;
-                asm volatile("" : "+v"(qmb_v));
-                const uint32_t oyuv = OYUV;
-                const uint32_t py = oyuv + lrow;
-                const uint32_t pc = oyuv + plane_y + (uint32_t)(j >> 3) * plane_c + (uint32_t)((row * 8 + (j & 7)) * cpitch + (mbx & ~3) * 8);
-                const uint32_t prgb = ORGB + lrow * 3u;
                 n_st = 0;
-                if (mbx & 1) {
-                    // ---- pair flush: exactly VM_PAIR store instructions ----
-                    if (valid) {
-                        asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2\n\ts_nop 1" : : "v"(py), "v"(st_y), "s"(gyuv) : "memory");
-                        asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 offset:16\n\ts_nop 1" : : "v"(py), "v"(yq), "s"(gyuv) : "memory");
-                    }
-                    if (RGB) {
-                        v4i a0, a1, a2;
-                        const uint4 y0 = make_uint4((uint32_t)st_y.x, (uint32_t)st_y.y, (uint32_t)st_y.z, (uint32_t)st_y.w);
-                        rgb16(y0, st_cb, st_cr, a0, a1, a2);
-                        if (valid) {
-                            asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2\n\ts_nop 1" : : "v"(prgb), "v"(a0), "s"(grgb) : "memory");
-                            asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 offset:16\n\ts_nop 1" : : "v"(prgb), "v"(a1), "s"(grgb) : "memory");
-                            asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 offset:32\n\ts_nop 1" : : "v"(prgb), "v"(a2), "s"(grgb) : "memory");
-                        }
-                        rgb16(yv, cbv, crv, a0, a1, a2);
-                        if (valid) {
-                            asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 offset:48\n\ts_nop 1" : : "v"(prgb), "v"(a0), "s"(grgb) : "memory");
-                            asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 offset:64\n\ts_nop 1" : : "v"(prgb), "v"(a1), "s"(grgb) : "memory");
-                            asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 offset:80\n\ts_nop 1" : : "v"(prgb), "v"(a2), "s"(grgb) : "memory");
-                        }
-                    }
-                    n_st = VM_PAIR;
+                if (mbi == 3 || mbx == W - 1) {
+                    uint32_t qmb_v = qmb;
+                    asm volatile("" : "+v"(qmb_v));
+                    const uint32_t oyuv = OYUV;
+                    const uint32_t lrow = (uint32_t)((row * 16 + j) * pitch + (mbx & ~3) * 16);   // inside the luma plane
+                    const uint32_t py = oyuv + lrow;
+                    const uint32_t pc = oyuv + plane_y + (uint32_t)(j >> 3) * plane_c + (uint32_t)((row * 8 + (j & 7)) * cpitch + (mbx & ~3) * 8);
+                    const uint32_t prgb = ORGB + lrow * 3u;
+                    const uint2 *own = reinterpret_cast<const uint2 *>(&Q.SC[j >> 3][(j & 7) * 24]);   // parked: this lane's chroma row
+                    const uint2 *pcb = reinterpret_cast<const uint2 *>(&Q.SC[0][(j >> 1) * 24]);        // parked: rows for the RGB conversion
+                    const uint2 *pcr = reinterpret_cast<const uint2 *>(&Q.SC[1][(j >> 1) * 24]);
                     if (mbi == 3) {
-                        // ---- chroma of four macroblocks: exactly two more store instructions ----
-                        const v4i c01 = {st_c0.x, st_c0.y, st_c1.x, st_c1.y}, c23 = {st_c2.x, st_c2.y, cq.x, cq.y};
+                        // ---- full strip: exactly VM_STRIP store instructions ----
+                        const uint2 w0 = own[0], w1 = own[1], w2 = own[2];
+                        const v4i c01 = {(int)w0.x, (int)w0.y, (int)w1.x, (int)w1.y}, c23 = {(int)w2.x, (int)w2.y, cq.x, cq.y};
                         if (valid) {
+                            asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2\n\ts_nop 1" : : "v"(py), "v"(st_y0), "s"(gyuv) : "memory");
+                            asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 offset:16\n\ts_nop 1" : : "v"(py), "v"(st_y1), "s"(gyuv) : "memory");
+                            asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 offset:32\n\ts_nop 1" : : "v"(py), "v"(st_y2), "s"(gyuv) : "memory");
+                            asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 offset:48\n\ts_nop 1" : : "v"(py), "v"(yq), "s"(gyuv) : "memory");
                             asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2\n\ts_nop 1" : : "v"(pc), "v"(c01), "s"(gyuv) : "memory");
                             asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 offset:16\n\ts_nop 1" : : "v"(pc), "v"(c23), "s"(gyuv) : "memory");
                         }
-                        n_st = VM_QUAD;
-                    } else {
-                        st_c1 = cq;
-                        if (mbx == W - 1) { // W % 4 == 2: two macroblocks of chroma left (compiler-counted stores)
-                            if (valid) {
-                                *reinterpret_cast<v2i *>(gyuv + pc) = st_c0;
-                                *reinterpret_cast<v2i *>(gyuv + pc + 8) = st_c1;
+                        if (RGB) {
+#define MVHP_RGB_OUT(YQ, CB, CR, OFF)                                                                                  \
+                            {                                                                                          \
+                                v4i a0, a1, a2;                                                                        \
+                                const uint4 yy = make_uint4((uint32_t)(YQ).x, (uint32_t)(YQ).y, (uint32_t)(YQ).z, (uint32_t)(YQ).w); \
+                                MVHP_RGB16(yy, CB, CR, a0, a1, a2);                                                    \
+                                if (MVHP_RGB_STORE_COND) {                                                             \
+                                    asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 offset:" #OFF "\n\ts_nop 1" : : "v"(prgb), "v"(a0), "s"(grgb) : "memory"); \
+                                    asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 offset:" #OFF "+16\n\ts_nop 1" : : "v"(prgb), "v"(a1), "s"(grgb) : "memory"); \
+                                    asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 offset:" #OFF "+32\n\ts_nop 1" : : "v"(prgb), "v"(a2), "s"(grgb) : "memory"); \
+                                } else {                                                                               \
+                                    asm volatile("" : : "v"(a0), "v"(a1), "v"(a2));                                    \
+                                }                                                                                      \
                             }
-                            n_st = 0;
+#if defined(MVHP_ABL_NO_RGB_MATH)
+#define MVHP_RGB16(yy, CB, CR, a0, a1, a2) { a0 = v4i{(int)yy.x, (int)yy.y, (int)yy.z, (int)yy.w}; a1 = a0; a2 = a0; }
+#else
+#define MVHP_RGB16(yy, CB, CR, a0, a1, a2) rgb16(yy, CB, CR, a0, a1, a2)
+#endif
+#if defined(MVHP_ABL_NO_RGB_STORE)
+#define MVHP_RGB_STORE_COND false
+#else
+#define MVHP_RGB_STORE_COND valid
+#endif
+                            MVHP_RGB_OUT(st_y0, pcb[0], pcr[0], 0)
+                            MVHP_RGB_OUT(st_y1, pcb[1], pcr[1], 48)
+                            MVHP_RGB_OUT(st_y2, pcb[2], pcr[2], 96)
+                            MVHP_RGB_OUT(yq, cbv, crv, 144)
+#undef MVHP_RGB_OUT
+#undef MVHP_RGB16
+#undef MVHP_RGB_STORE_COND
                         }
-                    }
-                } else if (mbx == W - 1) {
-                    // ---- odd picture width: the last macroblock leaves alone (compiler-counted stores) ----
-                    if (valid) {
-                        *reinterpret_cast<v4i *>(gyuv + py) = yq;
-                        if (mbi == 0) *reinterpret_cast<v2i *>(gyuv + pc) = cq;
-                        else { // mbi == 2
-                            *reinterpret_cast<v2i *>(gyuv + pc) = st_c0;
-                            *reinterpret_cast<v2i *>(gyuv + pc + 8) = st_c1;
-                            *reinterpret_cast<v2i *>(gyuv + pc + 16) = cq;
-                        }
-                    }
-                    if (RGB) {
-                        v4i a0, a1, a2;
-                        rgb16(yv, cbv, crv, a0, a1, a2);
-                        if (valid) {
-                            v4i *dst = reinterpret_cast<v4i *>(grgb + prgb);
-                            dst[0] = a0; dst[1] = a1; dst[2] = a2;
+                        n_st = VM_STRIP;
+                    } else {
+                        // ---- short strip at the right picture edge (W % 4 != 0): compiler-counted stores ----
+#pragma unroll
+                        for (int k = 0; k < 3; k++) {
+                            if (k > mbi) continue;
+                            const bool last = (k == mbi);
+                            const v4i yk = last ? yq : (k == 0 ? st_y0 : st_y1);
+                            const uint2 ow = own[k], pb = pcb[k], pr = pcr[k];   // read first, then choose values (not addresses)
+                            uint2 ck, cbk, crk;
+                            ck.x = last ? cv.x : ow.x; ck.y = last ? cv.y : ow.y;
+                            cbk.x = last ? cbv.x : pb.x; cbk.y = last ? cbv.y : pb.y;
+                            crk.x = last ? crv.x : pr.x; crk.y = last ? crv.y : pr.y;
+                            if (valid) {
+                                *reinterpret_cast<v4i *>(gyuv + py + k * 16) = yk;
+                                *reinterpret_cast<uint2 *>(gyuv + pc + k * 8) = ck;
+                            }
+                            if (RGB) {
+                                v4i a0, a1, a2;
+                                const uint4 yy = make_uint4((uint32_t)yk.x, (uint32_t)yk.y, (uint32_t)yk.z, (uint32_t)yk.w);
+                                rgb16(yy, cbk, crk, a0, a1, a2);
+                                if (valid) {
+                                    v4i *dst = reinterpret_cast<v4i *>(grgb + prgb + k * 48);
+                                    dst[0] = a0; dst[1] = a1; dst[2] = a2;
+                                }
+                            }
                         }
                     }
                 } else {
-                    // ---- even macroblock: park ----
-                    st_y = yq;
-                    st_cb = cbv;
-                    st_cr = crv;
-                    if (mbi == 0) st_c0 = cq; else st_c2 = cq;
+                    // ---- park: luma row in a register, chroma row in the LDS strip ----
+                    *reinterpret_cast<uint2 *>(&Q.SC[j >> 3][(j & 7) * 24 + mbi * 8]) = cv;
+                    if (mbi == 0) st_y0 = yq;
+                    else if (mbi == 1) st_y1 = yq;
+                    else st_y2 = yq;
                 }
             }
 

@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
-"""Static check of the quad kernel's ISA: between the prefetch loads (inline asm) and the guarded wait at the top
-of the next macroblock step, no instruction may read or write the prefetch registers, and exactly VM_STORES
-vector-memory instructions must be issued.  usage: check_prefetch_hazard.py file.s"""
+"""Static check of the quad kernel's ISA.  The record prefetch lives in v100-v123, registers that only inline assembly
+names (the compiler is limited to v0-v99 by amdgpu_num_vgpr): (a) no compiler-generated instruction may touch them;
+(b) the guarded wait in front of their use is `s_waitcnt vmcnt(N)` with N = the number of stores a full-strip step
+issues behind the prefetch, so exactly N asm stores must sit in the macroblock loop; (c) no scratch access (register
+spill = a vector-memory operation the counted waits do not know about) may sit in that loop.
+usage: check_prefetch_hazard.py file.s"""
 import re
 import sys
 
@@ -15,13 +18,38 @@ def regs(tok):
     return out
 
 
+PREFETCH = set(range(100, 124))
+
+
 def check(L, name):
     """L = the lines of one kernel."""
-    waits = [i for i, l in enumerate(L) if re.search(r's_waitcnt vmcnt\(\d+\)', l) and 'v_mov_b64 ' in L[i + 1]]
-    assert len(waits) == 3, (name, waits)
+    in_asm, touched, asm_loads, asm_stores_at = False, [], [], []
+    for i, raw in enumerate(L):
+        if '#ASMSTART' in raw:
+            in_asm = True
+            continue
+        if '#ASMEND' in raw:
+            in_asm = False
+            continue
+        l = raw.split(';')[0]
+        if not l.strip() or l.strip().startswith('.'):
+            continue
+        if in_asm:
+            if re.match(r'\s+global_load_dwordx4', l):
+                asm_loads.append(i)
+                assert regs(l.split(',')[0]) <= PREFETCH, (name, l)
+            elif re.match(r'\s+global_store', l):
+                asm_stores_at.append(i)
+                assert not (regs(l) & PREFETCH), (name, l)
+        elif regs(l) & PREFETCH:
+            touched.append((i, l))
+    assert len(asm_loads) == 12, (name, len(asm_loads))      # 6 in the prologue + 6 in the loop
+    # the guarded waits: asm blocks that start with s_waitcnt vmcnt(N) and then move v100.. out
+    waits = [i for i, l in enumerate(L) if re.search(r's_waitcnt vmcnt\(\d+\)', l) and 'v[100:101]' in L[i + 1]]
+    assert len(waits) == 2, (name, waits)
     counts = sorted(int(re.search(r'vmcnt\((\d+)\)', L[w]).group(1)) for w in waits)
-    assert counts[0] == 0 and counts[2] == counts[1] + 2, (name, counts)
-    n_expect = counts[2]
+    assert counts[0] == 0 and counts[1] in (6, 18), (name, counts)
+    n_expect = counts[1]
     w0 = min(waits)
     # the macroblock loop: the nearest label above the waits that a later instruction branches back to
     labi, back = None, []
@@ -34,41 +62,21 @@ def check(L, name):
             labi = i
             break
     assert labi is not None, name
-    loads = [i for i, l in enumerate(L) if 'global_load_dwordx2' in l and i > max(waits)]
-    assert len(loads) == 12, (name, len(loads))
-    dest = set()
-    for i in loads:
-        dest |= regs(L[i].split(',')[0])
-    bad, asm_stores = [], 0
-    in_asm = False
-    for i in list(range(loads[-1] + 1, max(back) + 1)) + list(range(labi, w0)):
-        raw = L[i]
-        if '#ASMSTART' in raw:
-            in_asm = True
-        if '#ASMEND' in raw:
-            in_asm = False
-        l = raw.split(';')[0]
-        if not l.strip() or l.strip().startswith('.'):
-            continue
-        if in_asm and re.match(r'\s+global_store', l):
-            asm_stores += 1
-        if regs(l) & dest:
-            bad.append((i, l))
-    for i in range(loads[0], loads[-1] + 1):
-        l = L[i].split(';')[0]
-        if 'global_load' in l or not l.strip():
-            continue
-        if regs(l) & dest:
-            bad.append((i, l))
-    # register spills (scratch_*) are vector-memory operations too: none may sit inside the macroblock loop
+    # (a) while the loads are in flight -- from the load block of the loop to the back edge, and from the loop head to
+    #     the waits -- the compiler must not use v100-v123 (it may use them as scratch registers between a wait and
+    #     the next load block: the record has been moved out, the loads are not issued yet)
+    loop_loads = [i for i in asm_loads if i > max(waits)]
+    assert len(loop_loads) == 6, (name, loop_loads)
+    bad = [(i, l) for i, l in touched if loop_loads[0] <= i <= max(back) or labi <= i <= max(waits)]
+    assert not bad, (name, 'compiler code touches the prefetch registers while loads are in flight', bad[:5])
+    pro = [i for i in asm_loads if i < labi]
+    bad = [(i, l) for i, l in touched if pro and pro[0] <= i < labi]
+    assert not bad, (name, 'compiler code touches the prefetch registers behind the prologue loads', bad[:5])
     spills = [i for i in range(labi, max(back) + 1) if re.match(r'\s+scratch_', L[i])]
     assert not spills, (name, 'scratch access inside the macroblock loop', spills[:3])
-    # the two wait blocks themselves read the prefetch registers (that is their job); nothing else may
-    bad = [(i, l) for i, l in bad if not any(w < i <= w + 12 for w in waits)]
-    assert not bad, (name, bad[:5])
-    # every asm store of the loop lies on the path of the step that parks nothing: pair flush + chroma flush
-    assert asm_stores == n_expect, (name, asm_stores, n_expect)
-    return n_expect, len(dest)
+    in_loop = [i for i in asm_stores_at if labi <= i <= max(back)]
+    assert len(in_loop) == len(asm_stores_at) == n_expect, (name, len(in_loop), len(asm_stores_at), n_expect)
+    return n_expect, len(asm_loads)
 
 
 def main(path):
@@ -79,7 +87,7 @@ def main(path):
         e = next(i for i in range(s, len(text)) if 's_endpgm' in text[i])
         name = text[s].split(':')[0]
         n, nd = check(text[s:e], name)
-        print("ok", name, "stores", n, "prefetch registers", nd)
+        print("ok", name, "stores per full strip", n, "asm loads", nd)
 
 
 if __name__ == "__main__":
