@@ -450,11 +450,11 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_num_vgpr(100))) void
 #pragma unroll
                         for (int i = 0; i < 8; i++) r2[i] = 0;
                     }
-                    if (kind == MVHP_KIND_I4x4) {
-                        *reinterpret_cast<int4 *>(&Q.res[j * 16]) = make_int4(r2[0], r2[1], r2[2], r2[3]);
-                        *reinterpret_cast<int4 *>(&Q.res[j * 16 + 8]) = make_int4(r2[4], r2[5], r2[6], r2[7]);
-                    }
                 }
+            }
+            if (kind == MVHP_KIND_I4x4) {   // lane-per-block -> lane-per-sample goes through LDS (zeros when there is no residual)
+                *reinterpret_cast<int4 *>(&Q.res[j * 16]) = make_int4(r2[0], r2[1], r2[2], r2[3]);
+                *reinterpret_cast<int4 *>(&Q.res[j * 16 + 8]) = make_int4(r2[4], r2[5], r2[6], r2[7]);
             }
             if (any_c) {
                 // ---- chroma 4x4 + transform_2x2_chromadc (h264_transform.c:827-860, :924-936, :988-1005) ----
@@ -641,18 +641,18 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_num_vgpr(100))) void
                     const uint32_t req = (REQ >> (min(mode, 8u) * 3)) & 7u;
                     const uint32_t ok = (((req & ~avail) == 0u) && (mode < 9u)) ? 1u : 0u; // else the prediction stays 0 (:442)
                     const uint32_t trow = (((av_upright >> j) & 1u) ? 0u : 9u) + min(mode, 8u);
-                    info = (avail & 3u) | ((mode == 2u) ? 4u : 0u) | (ok << 3) | ((trow * 64u) << 8);
+                    // bit 31: the mode is DC; bit 3: prediction allowed; bits 8..: tap table row offset
+                    info = ((mode == 2u) ? 0x80000000u : 0u) | (ok << 3) | ((trow * 64u) << 8);
                 }
                 const int pix = (j >> 2) * 32 + (j & 3);   // this lane's sample inside a block, tile units
                 const uint8_t *T = Q.T;
                 const uint8_t *tapb = reinterpret_cast<const uint8_t *>(B.tap4) + j * 4;
-                const bool has_res = need_l;
                 // software pipeline: control word, table entry and residual of block b+1 are fetched before block
-                // b's dependent tile reads
+                // b's dependent tile reads (the residual array holds zeros when the macroblock has none)
                 const int qbase4 = (lane & 48) << 2;
                 uint32_t inf = quarter_bcast(info, qbase4, 0);
-                uint32_t e_nx = *reinterpret_cast<const uint32_t *>(tapb + (inf >> 8));
-                int r_nx = has_res ? (int)Q.res[j] : 0;
+                uint32_t e_nx = *reinterpret_cast<const uint32_t *>(tapb + ((inf >> 8) & 0xffffu));
+                int r_nx = (int)Q.res[j];
 #pragma unroll
                 for (int blk = 0; blk < 16; blk++) {
                     const int bxO = (((blk >> 2) & 1) << 3) | ((blk & 1) << 2);
@@ -663,21 +663,29 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_num_vgpr(100))) void
                     const int r = r_nx;
                     if (blk < 15) {
                         inf = quarter_bcast(info, qbase4, blk + 1);
-                        e_nx = *reinterpret_cast<const uint32_t *>(tapb + (inf >> 8));
-                        r_nx = has_res ? (int)Q.res[(blk + 1) * 16 + j] : 0;
+                        e_nx = *reinterpret_cast<const uint32_t *>(tapb + ((inf >> 8) & 0xffffu));
+                        r_nx = (int)Q.res[(blk + 1) * 16 + j];
                     }
-                    const int okmask = (cur & 8u) ? -1 : 0;
+                    const int okmask = ((int)(cur << 28)) >> 31;   // bit 3 -> 0 / -1
                     const int ta = T[base - 33 + (int)(e & 255)];
                     const int tb = T[base - 33 + (int)((e >> 8) & 255)];
                     const int tc = T[base - 33 + (int)(e >> 16)];
                     int pred = ((ta + 2 * tb + tc + 2) >> 2) & okmask;
-                    if (__builtin_amdgcn_ballot_w64((cur & 4u) != 0) != 0) { // some quarter predicts DC
-                        const int sumH = sum4(*reinterpret_cast<const uint32_t *>(&T[base - 32]));
-                        const int sumV = T[base - 1] + T[base + 31] + T[base + 63] + T[base + 95];
-                        const uint32_t lu = cur & 3u; // 3 both, 1 left only, 2 up only, 0 none
-                        const int both = (sumH + sumV + 4) >> 3, l = (sumV + 2) >> 2, u = (sumH + 2) >> 2;
-                        const int dcv = (lu == 3u) ? both : (lu == 1u) ? l : (lu == 2u) ? u : 128;
-                        if (cur & 4u) pred = dcv;
+                    const bool isdc = (int)cur < 0;
+                    if (__builtin_amdgcn_ballot_w64(isdc) != 0) { // some quarter predicts DC
+                        // which neighbours exist is positional, i.e. the same for the four pictures: scalar branches
+                        const bool bl = (bxO > 0) || A, bu = (byO > 0) || Bv;
+                        int dcv = 128;
+                        if (bl && bu) {
+                            const int sumH = sum4(*reinterpret_cast<const uint32_t *>(&T[base - 32]));
+                            const int sumV = T[base - 1] + T[base + 31] + T[base + 63] + T[base + 95];
+                            dcv = (sumH + sumV + 4) >> 3;
+                        } else if (bl) {
+                            dcv = (T[base - 1] + T[base + 31] + T[base + 63] + T[base + 95] + 2) >> 2;
+                        } else if (bu) {
+                            dcv = (sum4(*reinterpret_cast<const uint32_t *>(&T[base - 32])) + 2) >> 2;
+                        }
+                        pred = isdc ? dcv : pred;
                     }
                     Q.T[base + pix] = (uint8_t)clip255(pred + r);
                     WAVE_SYNC();
