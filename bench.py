@@ -55,19 +55,22 @@ def parse_args():
     return ap.parse_args()
 
 
+PMC_SUMMARY = "r01_v5_pmc_summary.json"
+
+
 def measured_traffic(args, fused, kernel):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes of THIS command
     (tools/pmc_profile.sh: FETCH_SIZE and WRITE_SIZE in separate passes; FETCH_SIZE doubled per the gfx950
     correction in MI355X_MICROARCH.md).  Only reported when the run uses the profiled configuration."""
-    path = os.path.join(ROOT, "profiles", "r01_v4_pmc_summary.json")
+    path = os.path.join(ROOT, "profiles", PMC_SUMMARY)
     default = (args.frames == 2048 and args.width_mbs == 120 and args.height_mbs == 68 and args.profile == "baseline"
-               and args.density == "dense" and args.source == "stream" and fused and not args.waves)
+               and args.density == "dense" and args.source == "stream" and fused and not args.waves and args.layout == "auto")
     if not (default and os.path.exists(path)):
         return None, None
-    d = json.load(open(path)).get("recon_rows_kernel" if "recon" in kernel else "ycbcr_to_rgb_kernel", {})
+    d = json.load(open(path)).get(kernel.split(" ")[0], {})
     if "hbm_read_bytes_corrected" not in d or "hbm_write_bytes" not in d:
         return None, None
-    return d["hbm_read_bytes_corrected"] + d["hbm_write_bytes"], "profiles/r01_v4_pmc_summary.json"
+    return d["hbm_read_bytes_corrected"] + d["hbm_write_bytes"], "profiles/" + PMC_SUMMARY
 
 
 def cpu_baseline(params, rec, want_rgb, budget_s):
@@ -154,6 +157,10 @@ def main():
     if args.waves:
         hot.set_waves_per_picture(args.waves)
     hot.set_layout(args.layout)
+    # which reconstruction kernel the library picks (mirrors pick_quad() in hotpath_abi.hip: speed only)
+    n_cus = torch.cuda.get_device_properties(dev).multi_processor_count
+    quad = args.layout == "quad" or (args.layout == "auto" and F >= 4 * n_cus)
+    recon_name = "recon_quad_kernel" if quad else "recon_rows_kernel"
     fused = want_rgb and not args.no_fused
     hot.set_fused_color(fused)
     # a dedicated (non-null) stream: the C-ABI treats a NULL stream as "the context's own stream",
@@ -220,7 +227,7 @@ def main():
         bpm = BYTES_PER_MB_FUSED if fused else BYTES_PER_MB_RECON
         if dom_recon:
             achieved = mbs_per_step * bpm / (ms_recon * 1e-3) / 1e9
-            kname = "recon_rows_kernel" + (" (fused RGB epilogue)" if fused else "")
+            kname = recon_name + (" (fused RGB epilogue)" if fused else "")
         else:
             achieved = mbs_per_step * BYTES_PER_MB_COLOR / (ms_color * 1e-3) / 1e9
             kname = "ycbcr_to_rgb_kernel"
@@ -248,10 +255,11 @@ def main():
                 "frames_per_gpu_per_step": F,
                 "macroblocks_per_step": world * mbs_per_step,
                 "stages": "dequant+IDCT+intra prediction+reconstruct -> planar YCbCr" + (" -> RGB" if want_rgb else ""),
-                "parallelism": f"frame-per-workgroup, {world} GPU(s), no collectives",
+                "parallelism": (("four pictures per workgroup (16 lanes per picture)" if quad else "one picture per workgroup")
+                                + f", pictures sharded over {world} GPU(s), no collectives"),
                 "bit_exact_vs_oracle": ok,
             },
-            "kernel_ms": {"recon_rows_kernel": ms_recon, "ycbcr_to_rgb_kernel": ms_color},
+            "kernel_ms": {recon_name: ms_recon, "ycbcr_to_rgb_kernel": ms_color},
             "host_frontend": None if host_rate is None else {
                 "macroblocks_per_s_one_thread": host_rate, "stream_bytes_per_picture": stream_bytes / n_distinct,
                 "note": "entropy decode is outside the timed region (inputs resident in HBM)"},

@@ -12,6 +12,6 @@ import json
 for l in open('gpurun_out/sweep.log'):
     if l.startswith('##'): print(l.strip()); continue
     try:
-        d=json.loads(l); print("   value %.4g MB/s  ms/step %.3f  kernel_ms %.3f  frac %.3f ok=%s" % (d['value'], d['ms_per_step'], d['kernel_ms']['recon_rows_kernel'], d['roofline']['frac'], d['config']['bit_exact_vs_oracle']))
+        d=json.loads(l); print("   value %.4g MB/s  ms/step %.3f  kernel_ms %.3f  frac %.3f ok=%s" % (d['value'], d['ms_per_step'], [v for k,v in d['kernel_ms'].items() if k.startswith('recon')][0], d['roofline']['frac'], d['config']['bit_exact_vs_oracle']))
     except Exception as e: print("   ?", l[:200])
 PY
