@@ -408,16 +408,16 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_num_vgpr(100))) void
                 } else {
                     // ---- luma 4x4 (transform_4x4_residual, h264_transform.c:1049-1191) ----
                     int d[16];
-                    unpack8(cLA, d);
-                    unpack8(cLB, d + 8);
+                    const int pk[8] = {cLA.x, cLA.y, cLA.z, cLA.w, cLB.x, cLB.y, cLB.z, cLB.w};   // two levels per word
                     int dc = 0;
                     if (kind == MVHP_KIND_I16x16) {
                         // transform_16x16_lumadc, h264_transform.c:756-812 (incl. the `qP > 36` test): the 16 DC
                         // levels sit one per lane; rows/columns of the 4x4 DC matrix are lane bits (3,1) / (2,0)
+                        const int d0 = (int)(short)(pk[0] & 0xffff);
                         const int base = (lane & 48);
                         const int cj = ((j >> 1) & 2) | (j & 1), ci = ((j >> 2) & 2) | ((j >> 1) & 1);
                         const int aP = (base | (j & ~5) | ((j >> 2) & 1)) << 2;
-                        const int g = had4_lanes(d[0], dpp_quad<DPP_XOR1>(d[0]), cj, aP, aP | (4 << 2));
+                        const int g = had4_lanes(d0, dpp_quad<DPP_XOR1>(d0), cj, aP, aP | (4 << 2));
                         const int bP = (base | (j & ~10) | ((j >> 2) & 2)) << 2;
                         const int f = had4_lanes(g, dpp_quad<DPP_XOR2>(g), ci, bP, bP | (8 << 2));
                         const int lsA = B.ls0[qpy];
@@ -425,20 +425,23 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_num_vgpr(100))) void
                         else dc = (int)((unsigned)(f * lsA) + (1u << ((5 - s) & 31))) >> ((6 - s) & 31);
                     }
                     // quant4x4, h264_transform.c:1100-1134: ((c*LS + rnd) >> shr) << shl, the left shift folded into LS;
-                    // shr = rnd = 0 from qP 24 up (checked for the whole wave)
+                    // shr = rnd = 0 from qP 24 up (checked for the whole wave).  The levels are multiplied straight out
+                    // of the packed words (the 16-bit selection is an operand modifier of v_mul_i32_i24).
                     if (__builtin_amdgcn_ballot_w64(shr != 0) == 0) {
 #pragma unroll
                         for (int i = 0; i < 16; i++) {
                             const int r = i >> 2, c = i & 3;
                             const int ls = ((r & 1) == 0 && (c & 1) == 0) ? qt.x : (((r & 1) && (c & 1)) ? qt.y : qt.z);
-                            d[i] = __mul24(d[i], ls);
+                            const int lv = (i & 1) ? (pk[i >> 1] >> 16) : (int)(short)(pk[i >> 1] & 0xffff);
+                            d[i] = __mul24(lv, ls);
                         }
                     } else {
 #pragma unroll
                         for (int i = 0; i < 16; i++) {
                             const int r = i >> 2, c = i & 3;
                             const int ls = ((r & 1) == 0 && (c & 1) == 0) ? qt.x : (((r & 1) && (c & 1)) ? qt.y : qt.z);
-                            d[i] = (__mul24(d[i], ls) + rnd) >> shr;
+                            const int lv = (i & 1) ? (pk[i >> 1] >> 16) : (int)(short)(pk[i >> 1] & 0xffff);
+                            d[i] = (__mul24(lv, ls) + rnd) >> shr;
                         }
                     }
                     if (kind == MVHP_KIND_I16x16) d[0] = dc;
@@ -464,9 +467,9 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_num_vgpr(100))) void
                 const int4 qt = B.q4[qpc];
                 const int shr = qt.w & 255, rnd = (qt.w >> 8) & 255, s = (qt.w >> 16) & 255;
                 int d[16];
-                unpack8(cCA, d);
-                unpack8(cCB, d + 8);
-                const int c0 = dpp_quad<0x00>(d[0]), c1 = dpp_quad<0x55>(d[0]), c2v = dpp_quad<0xAA>(d[0]), c3 = dpp_quad<0xFF>(d[0]);
+                const int pk[8] = {cCA.x, cCA.y, cCA.z, cCA.w, cCB.x, cCB.y, cCB.z, cCB.w};   // two levels per word
+                const int d0 = (int)(short)(pk[0] & 0xffff);
+                const int c0 = dpp_quad<0x00>(d0), c1 = dpp_quad<0x55>(d0), c2v = dpp_quad<0xAA>(d0), c3 = dpp_quad<0xFF>(d0);
                 const int f = (k == 0) ? (c0 + c1 + c2v + c3) : (k == 1) ? (c0 - c1 + c2v - c3)
                             : (k == 2) ? (c0 + c1 - c2v - c3) : (c0 - c1 - c2v + c3);
                 const int dc = (int)((unsigned)(f * B.ls0[qpc]) << s) >> 5;
@@ -475,14 +478,16 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_num_vgpr(100))) void
                     for (int i = 1; i < 16; i++) {
                         const int r = i >> 2, c = i & 3;
                         const int ls = ((r & 1) == 0 && (c & 1) == 0) ? qt.x : (((r & 1) && (c & 1)) ? qt.y : qt.z);
-                        d[i] = __mul24(d[i], ls);
+                        const int lv = (i & 1) ? (pk[i >> 1] >> 16) : (int)(short)(pk[i >> 1] & 0xffff);
+                        d[i] = __mul24(lv, ls);
                     }
                 } else {
 #pragma unroll
                     for (int i = 1; i < 16; i++) {
                         const int r = i >> 2, c = i & 3;
                         const int ls = ((r & 1) == 0 && (c & 1) == 0) ? qt.x : (((r & 1) && (c & 1)) ? qt.y : qt.z);
-                        d[i] = (__mul24(d[i], ls) + rnd) >> shr;
+                        const int lv = (i & 1) ? (pk[i >> 1] >> 16) : (int)(short)(pk[i >> 1] & 0xffff);
+                        d[i] = (__mul24(lv, ls) + rnd) >> shr;
                     }
                 }
                 d[0] = dc + 32;
@@ -502,7 +507,11 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_num_vgpr(100))) void
             // =====================================================================================
             // wait for the row above: needs columns <= min(mbx+1, W-1); then fetch the top neighbours
             // =====================================================================================
+#if defined(MVHP_ABL_NO_WAIT)
+            if (false) {
+#else
             if (Bv) {
+#endif
                 const int need = up_base + min(mbx + 2, W);
                 int spins = 0;
                 while (__hip_atomic_load(&B.progress[up_wave], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < need) {
