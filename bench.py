@@ -159,7 +159,7 @@ def main():
     hot.set_layout(args.layout)
     # which reconstruction kernel the library picks (mirrors pick_quad() in hotpath_abi.hip: speed only)
     n_cus = torch.cuda.get_device_properties(dev).multi_processor_count
-    quad = args.layout == "quad" or (args.layout == "auto" and F >= 4 * n_cus)
+    quad = args.layout == "quad" or (args.layout == "auto" and F >= 3 * n_cus)
     recon_name = "recon_quad_kernel" if quad else "recon_rows_kernel"
     fused = want_rgb and not args.no_fused
     hot.set_fused_color(fused)

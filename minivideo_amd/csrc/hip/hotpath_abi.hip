@@ -176,8 +176,9 @@ static bool pick_quad(const mvhp_ctx *c, int n_frames)
 {
     if (c->layout == MVHP_LAYOUT_QUAD) return true;
     if (c->layout == MVHP_LAYOUT_ROWS) return false;
-    // speed only: four pictures per workgroup needs 4 * CUs pictures before every CU has work
-    return n_frames >= 4 * c->n_cus;
+    // speed only: four pictures per workgroup wants ~4 * CUs pictures before every CU has work; measured crossover
+    // against the one-picture kernel on 1080p: between 512 and 768 pictures
+    return n_frames >= 3 * c->n_cus;
 }
 
 static int pick_waves(const mvhp_ctx *c, const mvhp_stream_params_t *p, int n_frames, bool quad)
@@ -187,7 +188,12 @@ static int pick_waves(const mvhp_ctx *c, const mvhp_stream_params_t *p, int n_fr
         // speed only: the quad kernel is built for 4, 6, 8 and 12 waves (at 16 its register budget would force
         // spills); 8-wave workgroups fit two to a CU (LDS, 128 VGPRs) = 16 waves per CU
         static const int opts[4] = {12, 8, 6, 4};
-        if (nw == 0) nw = 8;
+        if (nw == 0) {
+            // two 8-wave workgroups per CU when there are enough workgroups and LDS for that, else one of 12
+            const int groups = (n_frames + 3) / 4;
+            const bool two_fit = 2 * mvhp::recon_quad_lds_bytes((int)p->width_mbs, 8) <= c->max_lds;
+            nw = (groups >= 2 * c->n_cus && two_fit) ? 8 : 12;
+        }
         for (int k = 0; k < 4; k++) {
             const int o = opts[k];
             if (o > nw) continue;
