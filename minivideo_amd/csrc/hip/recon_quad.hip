@@ -446,9 +446,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_num_vgpr(100))) void
                     }
                     if (kind == MVHP_KIND_I16x16) d[0] = dc;
                     d[0] += 32;
-                    idct4x4(d);
-#pragma unroll
-                    for (int i = 0; i < 8; i++) r2[i] = pack_res(d[2 * i], d[2 * i + 1]);
+                    idct4x4_packed(d, r2);
                     if (!need_l) {
 #pragma unroll
                         for (int i = 0; i < 8; i++) r2[i] = 0;
@@ -491,9 +489,11 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_num_vgpr(100))) void
                     }
                 }
                 d[0] = dc + 32;
-                idct4x4(d);
+                idct4x4_packed(d, c2);
+                if (!need_c) {
 #pragma unroll
-                for (int i = 0; i < 8; i++) c2[i] = need_c ? pack_res(d[2 * i], d[2 * i + 1]) : 0;
+                    for (int i = 0; i < 8; i++) c2[i] = 0;
+                }
             }
 
             {   // the record is consumed: prefetch the next macroblock of this wave -- same row, or the first of its
