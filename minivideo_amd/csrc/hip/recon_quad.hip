@@ -57,6 +57,9 @@ struct __attribute__((aligned(16))) QTables {
     uint32_t tap8[9 * 64];
 };
 
+#ifndef MVHP_RGB_HINT
+#define MVHP_RGB_HINT ""   // cache-policy suffix of the RGB stores (measurement builds try " nt" / " sc1")
+#endif
 typedef short s16x2 __attribute__((ext_vector_type(2)));
 typedef int v4i __attribute__((ext_vector_type(4)));   // native vectors: usable as inline-asm register operands
 typedef int v2i __attribute__((ext_vector_type(2)));
@@ -825,9 +828,9 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_num_vgpr(100))) void
                                 const uint4 yy = make_uint4((uint32_t)(YQ).x, (uint32_t)(YQ).y, (uint32_t)(YQ).z, (uint32_t)(YQ).w); \
                                 MVHP_RGB16(yy, CB, CR, a0, a1, a2);                                                    \
                                 if (MVHP_RGB_STORE_COND) {                                                             \
-                                    asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 offset:" #OFF "\n\ts_nop 1" : : "v"(prgb), "v"(a0), "s"(grgb) : "memory"); \
-                                    asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 offset:" #OFF "+16\n\ts_nop 1" : : "v"(prgb), "v"(a1), "s"(grgb) : "memory"); \
-                                    asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 offset:" #OFF "+32\n\ts_nop 1" : : "v"(prgb), "v"(a2), "s"(grgb) : "memory"); \
+                                    asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 offset:" #OFF MVHP_RGB_HINT "\n\ts_nop 1" : : "v"(prgb), "v"(a0), "s"(grgb) : "memory"); \
+                                    asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 offset:" #OFF "+16" MVHP_RGB_HINT "\n\ts_nop 1" : : "v"(prgb), "v"(a1), "s"(grgb) : "memory"); \
+                                    asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 offset:" #OFF "+32" MVHP_RGB_HINT "\n\ts_nop 1" : : "v"(prgb), "v"(a2), "s"(grgb) : "memory"); \
                                 } else {                                                                               \
                                     asm volatile("" : : "v"(a0), "v"(a1), "v"(a2));                                    \
                                 }                                                                                      \
