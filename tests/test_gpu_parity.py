@@ -103,3 +103,22 @@ def test_idempotent_and_frame_independent(hot):
     assert np.array_equal(yuv_all[2 * fb:5 * fb], yuv_sub)
     yuv_again, _ = hot.recon_host(params, rec, 6)
     assert np.array_equal(yuv_all, yuv_again)
+
+
+def test_random_configurations(hot):
+    """A short version of tools/soak_parity.py: random sizes, batch sizes, profiles, QP ranges and wave counts."""
+    rng = np.random.default_rng(2024)
+    try:
+        for _ in range(40):
+            W, H, n = int(rng.integers(1, 30)), int(rng.integers(1, 30)), int(rng.integers(1, 11))
+            lo = int(rng.integers(0, 40))
+            hi = int(rng.integers(lo, 52))
+            hot.set_waves_per_picture([0, 4, 6, 8, 12, 16][int(rng.integers(0, 6))])
+            params, rec = synth_packed(W, H, n, seed=int(rng.integers(0, 1 << 30)),
+                                       profile=["baseline", "high"][int(rng.integers(0, 2))],
+                                       density=["dense", "light"][int(rng.integers(0, 2))], qp_range=(lo, hi),
+                                       cqp_offsets=(int(rng.integers(-12, 13)), int(rng.integers(-12, 13))),
+                                       illegal_modes=bool(rng.random() < 0.2), allow_qp36_i16=bool(rng.random() < 0.5))
+            _check(hot, params, rec, n, want_rgb=bool(rng.integers(0, 2)))
+    finally:
+        hot.set_waves_per_picture(0)
