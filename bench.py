@@ -46,7 +46,7 @@ def parse_args():
                     help="stream: synthetic Annex-B stream -> host front end -> packed records (default); "
                          "records: random packed records drawn directly (minivideo_amd.synth)")
     ap.add_argument("--waves", type=int, default=0)
-    ap.add_argument("--layout", default="auto", choices=["auto", "rows", "quad"],
+    ap.add_argument("--layout", default="auto", choices=["auto", "rows", "quad", "oct"],
                     help="pictures per workgroup: rows = 1 (one wavefront per macroblock row), quad = 4 (16 lanes per picture)")
     ap.add_argument("--no-rgb", action="store_true")
     ap.add_argument("--no-fused", action="store_true", help="run the colour conversion as its own kernel")
@@ -160,7 +160,7 @@ def main():
     # which reconstruction kernel the library picks (mirrors pick_quad() in hotpath_abi.hip: speed only)
     n_cus = torch.cuda.get_device_properties(dev).multi_processor_count
     quad = args.layout == "quad" or (args.layout == "auto" and F >= 3 * n_cus)
-    recon_name = "recon_quad_kernel" if quad else "recon_rows_kernel"
+    recon_name = "recon_oct_kernel" if args.layout == "oct" else ("recon_quad_kernel" if quad else "recon_rows_kernel")
     fused = want_rgb and not args.no_fused
     hot.set_fused_color(fused)
     # a dedicated (non-null) stream: the C-ABI treats a NULL stream as "the context's own stream",

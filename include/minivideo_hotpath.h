@@ -181,10 +181,12 @@ MVHP_EXPORT int  mvhp_set_waves_per_picture(mvhp_ctx_t *ctx, int waves);
 /* Tuning knob (speed only, never results): how pictures map onto workgroups.
  * MVHP_LAYOUT_ROWS: one picture per workgroup, one wavefront per macroblock row (fills the chip from
  * ~256 pictures); MVHP_LAYOUT_QUAD: four pictures per workgroup, 16 lanes per picture (fewer
- * instructions per macroblock, wants >= ~1024 pictures); MVHP_LAYOUT_AUTO chooses from the batch size. */
+ * instructions per macroblock, wants >= ~768 pictures); MVHP_LAYOUT_OCT: eight pictures per workgroup, 8 lanes per
+ * picture (fewest instructions, wants >= ~2048 pictures); MVHP_LAYOUT_AUTO chooses from the batch size. */
 #define MVHP_LAYOUT_AUTO 0
 #define MVHP_LAYOUT_ROWS 1
 #define MVHP_LAYOUT_QUAD 2
+#define MVHP_LAYOUT_OCT  3
 MVHP_EXPORT int  mvhp_set_layout(mvhp_ctx_t *ctx, int layout);
 
 #ifdef __cplusplus

@@ -58,14 +58,15 @@ def build_product(force=False):
         objs.append(o)
     # the quad kernel keeps its record prefetch in registers that only inline assembly names: check, on the ISA these
     # very flags produce, that the compiler's code stays off them while loads are in flight (tools/check_prefetch_hazard.py)
-    quad = os.path.join(CSRC, "hip", "recon_quad.hip")
-    asm = os.path.join(objdir, "recon_quad.s")
-    if force or _newer(asm, [quad] + hdrs):
-        _run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wno-unused-value",
-              "--cuda-device-only", "-S", quad, "-o", asm] + inc)
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import check_prefetch_hazard
-    check_prefetch_hazard.main(asm)
+    for name in ("recon_quad", "recon_oct"):
+        src = os.path.join(CSRC, "hip", name + ".hip")
+        asm = os.path.join(objdir, name + ".s")
+        if force or _newer(asm, [src] + hdrs):
+            _run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wno-unused-value",
+                  "--cuda-device-only", "-S", src, "-o", asm] + inc)
+        check_prefetch_hazard.main(asm)
     _run([HIPCC, "--offload-arch=gfx950", "--hip-link", "-shared", "-fPIC", "-pthread", "-o", LIB] + objs)
     blob = open(LIB, "rb").read()
     if b"amdgcn-amd-amdhsa--gfx950" not in blob:

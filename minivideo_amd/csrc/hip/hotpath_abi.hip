@@ -109,6 +109,7 @@ MVHP_EXPORT int mvhp_create(int device, mvhp_ctx_t **out)
     if (const char *e = getenv("MINIVIDEO_LAYOUT")) { // tuning / test override, speed only
         if (!strcmp(e, "rows")) c->layout = MVHP_LAYOUT_ROWS;
         else if (!strcmp(e, "quad")) c->layout = MVHP_LAYOUT_QUAD;
+        else if (!strcmp(e, "oct")) c->layout = MVHP_LAYOUT_OCT;
     }
     c->n_cus = prop.multiProcessorCount;
     c->max_lds = prop.maxSharedMemoryPerMultiProcessor ? prop.maxSharedMemoryPerMultiProcessor : 65536;
@@ -145,7 +146,7 @@ MVHP_EXPORT int mvhp_set_waves_per_picture(mvhp_ctx_t *c, int waves)
 
 MVHP_EXPORT int mvhp_set_layout(mvhp_ctx_t *c, int layout)
 {
-    if (!c || layout < MVHP_LAYOUT_AUTO || layout > MVHP_LAYOUT_QUAD) return MVHP_FAILURE;
+    if (!c || layout < MVHP_LAYOUT_AUTO || layout > MVHP_LAYOUT_OCT) return MVHP_FAILURE;
     c->layout = layout;
     return MVHP_SUCCESS;
 }
@@ -172,19 +173,38 @@ MVHP_EXPORT int mvhp_set_fused_color(mvhp_ctx_t *c, int on)
     return MVHP_SUCCESS;
 }
 
-static bool pick_quad(const mvhp_ctx *c, int n_frames)
+static int pick_layout(const mvhp_ctx *c, const mvhp_stream_params_t *p, int n_frames)
 {
-    if (c->layout == MVHP_LAYOUT_QUAD) return true;
-    if (c->layout == MVHP_LAYOUT_ROWS) return false;
-    // speed only: four pictures per workgroup wants ~4 * CUs pictures before every CU has work; measured crossover
-    // against the one-picture kernel on 1080p: between 512 and 768 pictures
-    return n_frames >= 3 * c->n_cus;
+    int layout = c->layout;
+    if (layout == MVHP_LAYOUT_AUTO) {
+        // speed only: four pictures per workgroup wants ~4 * CUs pictures before every CU has work; measured crossover
+        // against the one-picture kernel on 1080p: between 512 and 768 pictures
+        layout = (n_frames >= 3 * c->n_cus) ? MVHP_LAYOUT_QUAD : MVHP_LAYOUT_ROWS;
+    }
+    // the batch kernels address a workgroup's pictures with 32-bit offsets and keep one line buffer per picture in LDS
+    const size_t mbs = (size_t)p->width_mbs * p->height_mbs;
+    if (layout == MVHP_LAYOUT_OCT && (mbs > ((size_t)1 << 19) || mvhp::recon_oct_lds_bytes((int)p->width_mbs, 4) > c->max_lds))
+        layout = MVHP_LAYOUT_QUAD;
+    if (layout == MVHP_LAYOUT_QUAD && mvhp::recon_quad_lds_bytes((int)p->width_mbs, 4) > c->max_lds) layout = MVHP_LAYOUT_ROWS;
+    return layout;
 }
 
-static int pick_waves(const mvhp_ctx *c, const mvhp_stream_params_t *p, int n_frames, bool quad)
+static int pick_waves(const mvhp_ctx *c, const mvhp_stream_params_t *p, int n_frames, int layout)
 {
     int nw = c->waves;
-    if (quad) {
+    if (layout == MVHP_LAYOUT_OCT) {
+        // speed only: built for 4, 6 and 8 waves; one workgroup per CU (LDS)
+        static const int opts[3] = {8, 6, 4};
+        if (nw == 0) nw = 8;
+        for (int k = 0; k < 3; k++) {
+            const int o = opts[k];
+            if (o > nw) continue;
+            if (o > 4 && ((o + 1) / 2 >= (int)p->height_mbs || mvhp::recon_oct_lds_bytes((int)p->width_mbs, o) > c->max_lds)) continue;
+            return o;
+        }
+        return 4;
+    }
+    if (layout == MVHP_LAYOUT_QUAD) {
         // speed only: the quad kernel is built for 4, 6, 8 and 12 waves (at 16 its register budget would force
         // spills); 8-wave workgroups fit two to a CU (LDS, 128 VGPRs) = 16 waves per CU
         static const int opts[4] = {12, 8, 6, 4};
@@ -226,10 +246,11 @@ static int launch_all(mvhp_ctx *c, const mvhp_stream_params_t *p, const void *d_
         a.cqp_off_cb = p->chroma_qp_index_offset;
         a.cqp_off_cr = p->second_chroma_qp_index_offset;
         a.n_frames = n_frames;
-        bool quad = pick_quad(c, n_frames);
-        if (quad && mvhp::recon_quad_lds_bytes(a.width_mbs, 4) > c->max_lds) quad = false; // four line buffers do not fit
-        const int nw = pick_waves(c, p, n_frames, quad);
-        if (quad) {
+        const int layout = pick_layout(c, p, n_frames);
+        const int nw = pick_waves(c, p, n_frames, layout);
+        if (layout == MVHP_LAYOUT_OCT) {
+            HIP_TRY(mvhp::launch_recon_oct(a, nw, st));
+        } else if (layout == MVHP_LAYOUT_QUAD) {
             HIP_TRY(mvhp::launch_recon_quad(a, nw, st));
         } else {
             if (mvhp::recon_lds_bytes(a.width_mbs, nw) > c->max_lds) {

@@ -71,6 +71,28 @@ __device__ __forceinline__ void emit_block(uint8_t *dst, int pitch, const uint32
     }
 }
 
+// The same with the residual packed by ROW pairs: r2[i], i = 4*y + x (y = 0, 1), holds the residuals of samples
+// (x, y) and (x, y + 2) -- the pairing of the eight-pictures kernel, where one lane predicts those two samples of
+// every Intra4x4 block.
+__device__ __forceinline__ void emit_block_ypairs(uint8_t *dst, int pitch, const uint32_t pw[4], const int r2[8])
+{
+    uint32_t o[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const int x = i & 3, y = i >> 2;
+        const uint32_t sel = (uint32_t)x | (0x0cu << 8) | ((uint32_t)(4 + x) << 16) | (0x0cu << 24);
+        const int pp = (int)__builtin_amdgcn_perm(pw[y + 2], pw[y], sel);          // pred(x,y) | pred(x,y+2) << 16
+        o[i] = sat_pk_u8(pk_add_sat(pp, r2[i]));                                   // byte 0: (x,y), byte 1: (x,y+2)
+    }
+#pragma unroll
+    for (int y = 0; y < 2; y++) {
+        const uint32_t t01 = __builtin_amdgcn_perm(o[4 * y + 1], o[4 * y + 0], 0x05010400u);
+        const uint32_t t23 = __builtin_amdgcn_perm(o[4 * y + 3], o[4 * y + 2], 0x05010400u);
+        *reinterpret_cast<uint32_t *>(dst + y * pitch) = __builtin_amdgcn_perm(t23, t01, 0x05040100u);
+        *reinterpret_cast<uint32_t *>(dst + (y + 2) * pitch) = __builtin_amdgcn_perm(t23, t01, 0x07060302u);
+    }
+}
+
 // Four plane-prediction samples clip255((v + k*b) >> 5), k = 0..3, as one row word (v_ashr_pk_u8_i32 shifts,
 // saturates to 0..255 and packs two samples).
 __device__ __forceinline__ uint32_t plane_row(int v, int b)

@@ -156,6 +156,39 @@ __device__ __forceinline__ void idct4x4_packed(int d[16], int out[8])
     }
 }
 
+// ... with the output packed by row pairs: out[i], i = 4*y + x (y = 0, 1), = residuals of samples (x, y) and (x, y + 2)
+__device__ __forceinline__ void idct4x4_ypairs(int d[16], int out[8])
+{
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        int e0 = d[i * 4 + 0] + d[i * 4 + 2];
+        int e1 = d[i * 4 + 0] - d[i * 4 + 2];
+        int e2 = (d[i * 4 + 1] >> 1) - d[i * 4 + 3];
+        int e3 = d[i * 4 + 1] + (d[i * 4 + 3] >> 1);
+        d[i * 4 + 0] = e0 + e3;
+        d[i * 4 + 1] = e1 + e2;
+        d[i * 4 + 2] = e1 - e2;
+        d[i * 4 + 3] = e0 - e3;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        int g0 = d[0 + j] + d[8 + j];
+        int g1 = d[0 + j] - d[8 + j];
+        int g2 = (d[4 + j] >> 1) - d[12 + j];
+        int g3 = d[4 + j] + (d[12 + j] >> 1);
+        d[0 + j]  = g0 + g3;
+        d[4 + j]  = g1 + g2;
+        d[8 + j]  = g1 - g2;
+        d[12 + j] = g0 - g3;
+    }
+    typedef short short2_t __attribute__((ext_vector_type(2)));
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const short2_t v = __builtin_amdgcn_cvt_pk_i16(d[i], d[i + 8]);
+        out[i] = __builtin_bit_cast(int, (short2_t)(v >> (short)6));
+    }
+}
+
 // 8-point butterfly of idct8x8 (h264_transform.c:1308-1342 / :1344-1378), in place.
 __device__ __forceinline__ void idct8_1d(int d[8])
 {

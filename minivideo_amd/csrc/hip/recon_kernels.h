@@ -27,6 +27,9 @@ hipError_t launch_recon(const ReconArgs &a, int n_frames, int nw, hipStream_t st
 // four pictures per workgroup, 16 lanes per picture (recon_quad.hip)
 size_t     recon_quad_lds_bytes(int width_mbs, int nw);
 hipError_t launch_recon_quad(const ReconArgs &a, int nw, hipStream_t stream);
+// eight pictures per workgroup, 8 lanes per picture (recon_oct.hip)
+size_t     recon_oct_lds_bytes(int width_mbs, int nw);
+hipError_t launch_recon_oct(const ReconArgs &a, int nw, hipStream_t stream);
 hipError_t launch_color(const ColorArgs &a, hipStream_t stream);
 
 } // namespace mvhp

@@ -1,0 +1,825 @@
+// recon_oct.hip -- the large-batch form of the reconstruction kernel (gfx950 only): EIGHT pictures per wavefront.
+//
+//   recon_oct_kernel<NW, RGB>   same contract as recon_quad_kernel / recon_rows_kernel: replaces
+//                               intra_prediction_process() (decoder/h264/h264_intra_prediction.c:112-145), all of
+//                               h264_transform.c, the planar gather of export.c:65-188 and mb_to_rgb()
+//                               (export_utils.c:209-324) for whole pictures.
+//
+// Mapping: as recon_quad.hip, with octets instead of quarters: octet o (8 lanes) of every wavefront works on picture
+// 8*blockIdx+o, wave w owns macroblock rows w, w+NW, ... of all eight.  Why eight: the reconstruction is bound by
+// VALU issue, and an instruction costs the same for 8 or 64 active lanes.  With 8 lanes per picture
+//   * the 16 dependent Intra4x4 block steps serve eight macroblocks (one lane predicts two samples of the block),
+//   * chroma (8 blocks of 4x4) keeps all lanes of the octet busy (16 lanes per picture left half of them idle),
+//   * everything that is paid once per step (header decoding, the row-above wait, neighbour bookkeeping) is shared
+//     by eight macroblocks.
+// Lane j of an octet owns luma 4x4 blocks 2j and 2j+1 (64 contiguous bytes of the record: for an Intra8x8 macroblock
+// the same bytes are rows 4(j&1)..+3 of 8x8 block j>>1), chroma block j, luma rows j and j+8 and chroma row j of
+// both planes of the finished macroblock.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "minivideo_hotpath.h"
+#include "recon_kernels.h"
+#include "recon_device.h"
+#include "recon_batch_device.h"
+
+namespace mvhp {
+
+// The compiler is left to the low registers (256 are available at two waves per SIMD; it needs ~190); v216-v247 are
+// the record prefetch registers, named only inside inline assembly (see recon_quad.hip and
+// tools/check_prefetch_hazard.py, which checks the ISA of every instantiation).
+template <int NW, bool RGB>
+__global__ __launch_bounds__(NW * 64) void recon_oct_kernel(ReconArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int W = a.width_mbs, H = a.height_mbs;
+    QTables &B = *reinterpret_cast<QTables *>(smem);
+    uint8_t *lines = smem + sizeof(QTables);              // [octet][ luma W*16 | Cb W*8 | Cr W*8 ]
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane_c = threadIdx.x & 63;
+    uint8_t *wave_lds = lines + (size_t)8 * W * 32 + (size_t)wave * 8 * sizeof(QLds);
+
+    // ---- one-time table setup (as recon_quad.hip) ----
+    for (int i = threadIdx.x; i < 52; i += NW * 64) {
+        const int m = i % 6, s = i / 6;
+        const int shl = max(s - 4, 0), shr = max(4 - s, 0), rnd = (1 << shr) >> 1;
+        int4 e;
+        e.x = (16 * c_v4x4[m * 3 + 0]) << shl;
+        e.y = (16 * c_v4x4[m * 3 + 1]) << shl;
+        e.z = (16 * c_v4x4[m * 3 + 2]) << shl;
+        e.w = shr | (rnd << 8) | (s << 16) | (m << 24);
+        B.q4[i] = e;
+        B.ls0[i] = 16 * c_v4x4[m * 3 + 0];
+    }
+    for (int i = threadIdx.x; i < 36; i += NW * 64) B.ls8[i] = 16 * c_v8x8[i];
+    for (int i = threadIdx.x; i < 64; i += NW * 64) B.qpc[i] = (uint8_t)((i < 30) ? i : c_qpc[min(i, 51) - 30]);
+    for (int i = threadIdx.x; i < 2 * 9 * 16; i += NW * 64)
+        B.tap4[i] = tap4_entry((i >> 4) % 9, i & 3, (i >> 2) & 3, i >= 9 * 16);
+    for (int i = threadIdx.x; i < 9 * 64; i += NW * 64) B.tap8[i] = tap8_entry(i >> 6, i & 7, (i >> 3) & 7);
+    if (threadIdx.x < 16) B.progress[threadIdx.x] = 0;
+    if (threadIdx.x == 16) B.abort_flag = 0;
+    __syncthreads();
+
+    const int pitch = W * 16, cpitch = W * 8;
+    const uint32_t plane_y = (uint32_t)W * H * 256, plane_c = (uint32_t)W * H * 64;
+    const int up_wave = (wave + NW - 1) % NW;
+
+    // this lane's picture; addresses = a scalar base per workgroup + a 32-bit per-lane offset (eight pictures of the
+    // largest supported size exceed 4 GiB of RGB: the launcher falls back to the quad kernel beyond 512 Ki macroblocks)
+    const int o_c = lane_c >> 3;
+    const int frame_raw = (int)blockIdx.x * 8 + o_c;
+    const bool valid = frame_raw < a.n_frames;            // a short last workgroup repeats the last picture, stores off
+    const int frame = min(frame_raw, a.n_frames - 1);
+    const uint32_t qf = (uint32_t)(frame - (int)blockIdx.x * 8);
+    const uint8_t *gpacked = a.packed + (size_t)blockIdx.x * 8 * W * H * MVHP_MB_BYTES;
+    uint8_t *gyuv = a.yuv + (size_t)blockIdx.x * 8 * W * H * 384;
+    uint8_t *grgb = a.rgb + (size_t)blockIdx.x * 8 * W * H * 768;
+    const uint32_t qmb = qf * (uint32_t)(W * H);
+#define OPACKED (__umul24(qmb_v, MVHP_MB_BYTES))
+#define OYUV (__umul24(qmb_v, 384u))
+#define ORGB (__umul24(qmb_v, 768u))
+
+    // Record prefetch, one macroblock ahead, in v216-v247: header (32 B), the lane's two luma blocks (64 B), its
+    // chroma block (32 B).  A step issues no store or exactly VM_STRIP stores behind the eight loads (`n_st`).
+#if defined(MVHP_ABL_NO_RGB_STORE)
+    constexpr int VM_STRIP = 12;
+#else
+    constexpr int VM_STRIP = RGB ? 36 : 12;   // a full strip: 2 rows x 4 luma + 2 x 2 chroma (+ 2 x 12 RGB) 16-byte stores
+#endif
+    auto prefetch = [&](int prow, int px, int lane_p) {
+        const int jj = lane_p & 7;
+        uint32_t qmb_v = qmb;
+        asm volatile("" : "+v"(qmb_v));
+        const uint32_t rec = OPACKED + (uint32_t)(prow * W + px) * MVHP_MB_BYTES;
+        const uint32_t recL = rec + MVHP_MB_HEADER_BYTES + jj * 64;
+        const uint32_t recC = rec + MVHP_MB_HEADER_BYTES + (16 + jj) * 32;
+        asm volatile("s_nop 4\n\t"
+                     "global_load_dwordx4 v[216:219], %0, %3\n\t"
+                     "global_load_dwordx4 v[220:223], %0, %3 offset:16\n\t"
+                     "global_load_dwordx4 v[224:227], %1, %3\n\t"
+                     "global_load_dwordx4 v[228:231], %1, %3 offset:16\n\t"
+                     "global_load_dwordx4 v[232:235], %1, %3 offset:32\n\t"
+                     "global_load_dwordx4 v[236:239], %1, %3 offset:48\n\t"
+                     "global_load_dwordx4 v[240:243], %2, %3\n\t"
+                     "global_load_dwordx4 v[244:247], %2, %3 offset:16"
+                     : : "v"(rec), "v"(recL), "v"(recC), "s"(gpacked)
+                     : "memory", "v216", "v217", "v218", "v219", "v220", "v221", "v222", "v223", "v224", "v225", "v226", "v227",
+                       "v228", "v229", "v230", "v231", "v232", "v233", "v234", "v235", "v236", "v237", "v238", "v239",
+                       "v240", "v241", "v242", "v243", "v244", "v245", "v246", "v247");
+    };
+    if (wave < H) prefetch(wave, 0, lane_c);
+    asm volatile("s_waitcnt vmcnt(0)" : : : "memory");   // (a wave without rows never reads the registers)
+
+    const int up_adj = __builtin_amdgcn_readfirstlane((wave == 0) ? -1 : 0); // wave 0 follows the last wave's previous pass
+    int done = 0;  // macroblocks completed by this wave
+    int n_st = 0;  // asm stores the previous step issued behind its prefetch (0 also when the compiler counted them)
+    // output strip: luma rows j and j+8 of three parked macroblocks (registers); their chroma rows live in LDS (Q.SC)
+    v4i st_a0 = {0, 0, 0, 0}, st_a1 = st_a0, st_a2 = st_a0, st_b0 = st_a0, st_b1 = st_a0, st_b2 = st_a0;
+
+    for (int row = wave; row < H; row += NW) {
+        const int pass = row / NW;
+        const int up_base = (pass + up_adj) * W; // MBs the upper wave finished before its row (row-1)
+        const bool Bv = row > 0;
+#pragma unroll 1
+        for (int mbx = 0; mbx < W; mbx++) {
+            int lane = lane_c;
+            asm volatile("" : "+v"(lane));   // re-materialised per macroblock: keeps lane-dependent addresses out of registers
+            const int o = lane >> 3, j = lane & 7;
+            QLds &Q = *reinterpret_cast<QLds *>(wave_lds + o * sizeof(QLds));
+            uint8_t *line_y = lines + (size_t)o * W * 32;
+            uint8_t *line_cb = line_y + W * 16;
+            uint8_t *line_cr = line_cb + W * 8;
+            const bool A = mbx > 0, C = Bv && (mbx < W - 1), D = A && Bv;
+
+            // wait for the prefetched record and move it into compiler-visible registers
+            v2i w[16];
+#define MVHP_WAIT_PREFETCH(N)                                                                                          \
+            asm volatile("s_waitcnt vmcnt(%16)\n\t"                                                                    \
+                         "v_mov_b64 %0, v[216:217]\n\tv_mov_b64 %1, v[218:219]\n\tv_mov_b64 %2, v[220:221]\n\t"         \
+                         "v_mov_b64 %3, v[222:223]\n\tv_mov_b64 %4, v[224:225]\n\tv_mov_b64 %5, v[226:227]\n\t"         \
+                         "v_mov_b64 %6, v[228:229]\n\tv_mov_b64 %7, v[230:231]\n\tv_mov_b64 %8, v[232:233]\n\t"         \
+                         "v_mov_b64 %9, v[234:235]\n\tv_mov_b64 %10, v[236:237]\n\tv_mov_b64 %11, v[238:239]\n\t"        \
+                         "v_mov_b64 %12, v[240:241]\n\tv_mov_b64 %13, v[242:243]\n\tv_mov_b64 %14, v[244:245]\n\t"       \
+                         "v_mov_b64 %15, v[246:247]"                                                                   \
+                         : "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2]), "=&v"(w[3]), "=&v"(w[4]), "=&v"(w[5]), "=&v"(w[6]),    \
+                           "=&v"(w[7]), "=&v"(w[8]), "=&v"(w[9]), "=&v"(w[10]), "=&v"(w[11]), "=&v"(w[12]),             \
+                           "=&v"(w[13]), "=&v"(w[14]), "=&v"(w[15])                                                    \
+                         : "n"(N)                                                                                      \
+                         : "memory")
+            if (n_st) MVHP_WAIT_PREFETCH(VM_STRIP);
+            else MVHP_WAIT_PREFETCH(0);
+#undef MVHP_WAIT_PREFETCH
+            const uint32_t h0 = (uint32_t)w[0].x, h1 = (uint32_t)w[0].y, nz = (uint32_t)w[1].x;
+            const uint32_t m0 = (uint32_t)w[1].y, m1 = (uint32_t)w[2].x, m2 = (uint32_t)w[2].y, m3 = (uint32_t)w[3].x;
+            const int kind = h0 & 255;
+            const int qpy = min((int)((h0 >> 8) & 255), 51);
+            const int cmode = (h0 >> 24) & 255, i16mode = h1 & 255;
+            // Intra16x16 at QP'Y == 36 yields a non-zero DC term even from all-zero levels
+            // (h264_transform.c:797-808), so the residual stage cannot be skipped there.
+            const bool quirk36 = (kind == MVHP_KIND_I16x16) && (qpy == 36);
+            const bool need_l = ((nz & 0xffffu) != 0) || quirk36;
+            const bool need_c = (nz & 0xff0000u) != 0;
+            const bool any_l = __builtin_amdgcn_ballot_w64(need_l) != 0;
+            const bool any_c = __builtin_amdgcn_ballot_w64(need_c) != 0;
+
+            // geometry of the lane's two luma blocks 2j (slot 0) and 2j+1 (slot 1): same rows, columns 4 apart
+            const int xO0 = ((j >> 1) & 1) << 3;           // slot s: xO0 + 4*s
+            const int yO = ((j >> 2) << 3) | ((j & 1) << 2);
+            const int obase4 = (lane & 56) << 2;            // byte address (ds_bpermute) of the octet's lane 0
+
+            // =====================================================================================
+            // residuals
+            // =====================================================================================
+            int r2[2][8];   // luma blocks 2j, 2j+1: residuals packed by row pairs (see idct4x4_ypairs)
+            int c2[8];      // chroma block j
+#pragma unroll
+            for (int i = 0; i < 8; i++) { r2[0][i] = 0; r2[1][i] = 0; c2[i] = 0; }
+            if (any_l) {
+                const int4 qt = B.q4[qpy];
+                const int shr = qt.w & 255, rnd = (qt.w >> 8) & 255, s = (qt.w >> 16) & 255, m = (qt.w >> 24) & 255;
+                if (kind == MVHP_KIND_I8x8) {
+                    // ---- luma 8x8 (transform_8x8_residual, h264_transform.c:1205-1383): lane j holds rows
+                    //      4*(j&1) .. +3 of 8x8 block j >> 1; rows in registers, columns after an LDS transpose,
+                    //      two blocks at a time ----
+                    const int hh = j & 1;
+                    const int *l8 = &B.ls8[m * 6];
+                    const int ls0 = l8[0], ls1 = l8[1], ls2 = l8[2], ls3 = l8[3], ls4 = l8[4], ls5 = l8[5];
+                    int dr[4][8];
+#pragma unroll
+                    for (int t = 0; t < 4; t++) {   // row 4*hh + t: its class pattern (h264.c:438-446) depends on t only
+                        const int pkw[4] = {w[4 + 2 * t].x, w[4 + 2 * t].y, w[5 + 2 * t].x, w[5 + 2 * t].y};
+                        const int k0 = (t == 0) ? ls0 : (t == 2) ? ls4 : ls3;   // columns 0, 4
+                        const int k1 = (t == 0) ? ls3 : (t == 2) ? ls5 : ls1;   // odd columns
+                        const int k2 = (t == 0) ? ls4 : (t == 2) ? ls2 : ls5;   // columns 2, 6
+#pragma unroll
+                        for (int c = 0; c < 8; c++) {
+                            const int lv = (c & 1) ? (pkw[c >> 1] >> 16) : (int)(short)(pkw[c >> 1] & 0xffff);
+                            const int ls = (c & 1) ? k1 : ((c & 3) == 0 ? k0 : k2);
+                            if (qpy > 35) dr[t][c] = (int)((unsigned)(lv * ls) << ((s - 6) & 31));
+                            else dr[t][c] = (lv * ls + (1 << ((5 - s) & 31))) >> ((6 - s) & 31);
+                        }
+                    }
+                    if (hh == 0) dr[0][0] += 32; // rounding term of the final (m + 32) >> 6, see idct4x4
+#pragma unroll
+                    for (int t = 0; t < 4; t++) idct8_1d(dr[t]);
+                    int col[2][2][8];
+#pragma unroll
+                    for (int h = 0; h < 2; h++) {
+                        if ((j >> 2) == h) {
+                            int32_t *dst = &Q.scr[((j >> 1) & 1) * 64 + hh * 32];
+#pragma unroll
+                            for (int t = 0; t < 4; t++) {
+                                *reinterpret_cast<int4 *>(dst + t * 8) = make_int4(dr[t][0], dr[t][1], dr[t][2], dr[t][3]);
+                                *reinterpret_cast<int4 *>(dst + t * 8 + 4) = make_int4(dr[t][4], dr[t][5], dr[t][6], dr[t][7]);
+                            }
+                        }
+                        WAVE_SYNC();
+#pragma unroll
+                        for (int i = 0; i < 8; i++) {
+                            const int2 v = *reinterpret_cast<const int2 *>(&Q.scr[(j >> 2) * 64 + i * 8 + (j & 3) * 2]);
+                            col[h][0][i] = v.x;
+                            col[h][1][i] = v.y;
+                        }
+                        idct8_1d(col[h][0]);
+                        idct8_1d(col[h][1]);
+                        WAVE_SYNC();
+                    }
+                    // res[blk8][row][column] (int16): lane j columns 2*(j&3), +1 of block 2h + (j >> 2)
+#pragma unroll
+                    for (int h = 0; h < 2; h++) {
+                        int32_t *dst = reinterpret_cast<int32_t *>(&Q.res[(2 * h + (j >> 2)) * 64 + (j & 3) * 2]);
+#pragma unroll
+                        for (int i = 0; i < 8; i++) dst[i * 4] = pack_res(col[h][0][i] >> 6, col[h][1][i] >> 6);
+                    }
+                } else {
+                    // ---- luma 4x4 (transform_4x4_residual, h264_transform.c:1049-1191), two blocks per lane ----
+                    int dc0 = 0, dc1 = 0;
+                    if (kind == MVHP_KIND_I16x16) {
+                        // transform_16x16_lumadc, h264_transform.c:756-812 (incl. the `qP > 36` test).  Block 2j+s sits at
+                        // DC-matrix column (j1, s) and row (j2, j0): the column transform is half in-lane (s), half
+                        // across lanes j ^ 2; the row transform runs across lanes (j0: quad_perm, j2: ds_bpermute).
+                        const int d00 = (int)(short)(w[4].x & 0xffff), d01 = (int)(short)(w[8].x & 0xffff);
+                        const int S = d00 + d01, Dd = d00 - d01;
+                        const int pS = dpp_quad<DPP_XOR2>(S), pD = dpp_quad<DPP_XOR2>(Dd);
+                        const bool x1 = (j & 2) != 0;
+                        const int u = x1 ? pD : S, v = x1 ? Dd : pS;
+                        const int g0 = x1 ? (u - v) : (u + v), g1 = x1 ? (u + v) : (u - v);
+                        const int ci = ((j >> 1) & 2) | (j & 1);
+                        const int aP = ((lane & 56) | (j & ~5) | ((j >> 2) & 1)) << 2;
+                        const int f0 = had4_lanes(g0, dpp_quad<DPP_XOR1>(g0), ci, aP, aP | (4 << 2));
+                        const int f1 = had4_lanes(g1, dpp_quad<DPP_XOR1>(g1), ci, aP, aP | (4 << 2));
+                        const int lsA = B.ls0[qpy];
+                        if (qpy > 36) {
+                            dc0 = (int)((unsigned)(f0 * lsA) << ((s - 6) & 31));
+                            dc1 = (int)((unsigned)(f1 * lsA) << ((s - 6) & 31));
+                        } else {
+                            dc0 = (int)((unsigned)(f0 * lsA) + (1u << ((5 - s) & 31))) >> ((6 - s) & 31);
+                            dc1 = (int)((unsigned)(f1 * lsA) + (1u << ((5 - s) & 31))) >> ((6 - s) & 31);
+                        }
+                    }
+                    const bool fast = __builtin_amdgcn_ballot_w64(shr != 0) == 0;   // shr = rnd = 0 from qP 24 up
+#pragma unroll
+                    for (int sl = 0; sl < 2; sl++) {
+                        const int pk[8] = {w[4 + 4 * sl].x, w[4 + 4 * sl].y, w[5 + 4 * sl].x, w[5 + 4 * sl].y,
+                                           w[6 + 4 * sl].x, w[6 + 4 * sl].y, w[7 + 4 * sl].x, w[7 + 4 * sl].y};
+                        int d[16];
+                        // quant4x4, h264_transform.c:1100-1134: ((c*LS + rnd) >> shr) << shl, the left shift folded into LS
+                        if (fast) {
+#pragma unroll
+                            for (int i = 0; i < 16; i++) {
+                                const int r = i >> 2, c = i & 3;
+                                const int ls = ((r & 1) == 0 && (c & 1) == 0) ? qt.x : (((r & 1) && (c & 1)) ? qt.y : qt.z);
+                                const int lv = (i & 1) ? (pk[i >> 1] >> 16) : (int)(short)(pk[i >> 1] & 0xffff);
+                                d[i] = __mul24(lv, ls);
+                            }
+                        } else {
+#pragma unroll
+                            for (int i = 0; i < 16; i++) {
+                                const int r = i >> 2, c = i & 3;
+                                const int ls = ((r & 1) == 0 && (c & 1) == 0) ? qt.x : (((r & 1) && (c & 1)) ? qt.y : qt.z);
+                                const int lv = (i & 1) ? (pk[i >> 1] >> 16) : (int)(short)(pk[i >> 1] & 0xffff);
+                                d[i] = (__mul24(lv, ls) + rnd) >> shr;
+                            }
+                        }
+                        if (kind == MVHP_KIND_I16x16) d[0] = sl ? dc1 : dc0;
+                        d[0] += 32;
+                        idct4x4_ypairs(d, r2[sl]);
+                    }
+                    if (!need_l) {
+#pragma unroll
+                        for (int i = 0; i < 8; i++) { r2[0][i] = 0; r2[1][i] = 0; }
+                    }
+                }
+            }
+            if (kind == MVHP_KIND_I4x4) {   // lane-per-block -> lane-per-sample-pair goes through LDS (zeros without residual)
+                int32_t *dst = reinterpret_cast<int32_t *>(&Q.res[j * 32]);
+                *reinterpret_cast<int4 *>(dst) = make_int4(r2[0][0], r2[0][1], r2[0][2], r2[0][3]);
+                *reinterpret_cast<int4 *>(dst + 4) = make_int4(r2[0][4], r2[0][5], r2[0][6], r2[0][7]);
+                *reinterpret_cast<int4 *>(dst + 8) = make_int4(r2[1][0], r2[1][1], r2[1][2], r2[1][3]);
+                *reinterpret_cast<int4 *>(dst + 12) = make_int4(r2[1][4], r2[1][5], r2[1][6], r2[1][7]);
+            }
+            if (any_c) {
+                // ---- chroma 4x4 + transform_2x2_chromadc (h264_transform.c:827-860, :924-936, :988-1005) ----
+                const int pl = j >> 2, k = j & 3;
+                const int qpi = min(max(qpy + (pl ? a.cqp_off_cr : a.cqp_off_cb), 0), 51);
+                const int qpc = B.qpc[qpi];
+                const int4 qt = B.q4[qpc];
+                const int shr = qt.w & 255, rnd = (qt.w >> 8) & 255, s = (qt.w >> 16) & 255;
+                int d[16];
+                const int pk[8] = {w[12].x, w[12].y, w[13].x, w[13].y, w[14].x, w[14].y, w[15].x, w[15].y};
+                const int d0 = (int)(short)(pk[0] & 0xffff);
+                const int c0 = dpp_quad<0x00>(d0), c1 = dpp_quad<0x55>(d0), c2v = dpp_quad<0xAA>(d0), c3 = dpp_quad<0xFF>(d0);
+                const int f = (k == 0) ? (c0 + c1 + c2v + c3) : (k == 1) ? (c0 - c1 + c2v - c3)
+                            : (k == 2) ? (c0 + c1 - c2v - c3) : (c0 - c1 - c2v + c3);
+                const int dc = (int)((unsigned)(f * B.ls0[qpc]) << s) >> 5;
+                if (__builtin_amdgcn_ballot_w64(shr != 0) == 0) {
+#pragma unroll
+                    for (int i = 1; i < 16; i++) {
+                        const int r = i >> 2, c = i & 3;
+                        const int ls = ((r & 1) == 0 && (c & 1) == 0) ? qt.x : (((r & 1) && (c & 1)) ? qt.y : qt.z);
+                        const int lv = (i & 1) ? (pk[i >> 1] >> 16) : (int)(short)(pk[i >> 1] & 0xffff);
+                        d[i] = __mul24(lv, ls);
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 1; i < 16; i++) {
+                        const int r = i >> 2, c = i & 3;
+                        const int ls = ((r & 1) == 0 && (c & 1) == 0) ? qt.x : (((r & 1) && (c & 1)) ? qt.y : qt.z);
+                        const int lv = (i & 1) ? (pk[i >> 1] >> 16) : (int)(short)(pk[i >> 1] & 0xffff);
+                        d[i] = (__mul24(lv, ls) + rnd) >> shr;
+                    }
+                }
+                d[0] = dc + 32;
+                idct4x4_ypairs(d, c2);
+                if (!need_c) {
+#pragma unroll
+                    for (int i = 0; i < 8; i++) c2[i] = 0;
+                }
+            }
+
+            {   // the record is consumed: prefetch the next macroblock of this wave -- same row, or the first of its
+                // next row (none left: this one again)
+                int nrow = row, nx = mbx + 1;
+                if (nx >= W) { nrow = row + NW; nx = 0; }
+                if (nrow >= H) { nrow = row; nx = mbx; }
+                prefetch(nrow, nx, lane);
+            }
+
+            // =====================================================================================
+            // wait for the row above: needs columns <= min(mbx+1, W-1); then fetch the top neighbours
+            // =====================================================================================
+            if (Bv) {
+                const int need = up_base + min(mbx + 2, W);
+                int spins = 0;
+                while (__hip_atomic_load(&B.progress[up_wave], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < need) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > (1 << 22) || __hip_atomic_load(&B.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
+                        if (lane == 0) { __hip_atomic_store(&B.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); atomicOr(a.err, 1u); }
+                        return;
+                    }
+                }
+                asm volatile("" ::: "memory");
+                // ten dwords per picture: lanes 0-3 luma top, 4-5 luma up-right (when C), 6-7 Cb top; then lanes 0-1 Cr top
+                if (C || (j >> 1) != 2) {
+                    uint8_t *dst;
+                    const uint8_t *src;
+                    if (j < 4) { dst = &Q.T[16 + j * 4]; src = &line_y[mbx * 16 + j * 4]; }
+                    else if (j < 6) { dst = &Q.T[32 + (j - 4) * 4]; src = &line_y[mbx * 16 + 16 + (j - 4) * 4]; }
+                    else { dst = &Q.TC[0][8 + (j - 6) * 4]; src = &line_cb[mbx * 8 + (j - 6) * 4]; }
+                    *reinterpret_cast<uint32_t *>(dst) = *reinterpret_cast<const uint32_t *>(src);
+                }
+                if (j < 2)
+                    *reinterpret_cast<uint32_t *>(&Q.TC[1][8 + j * 4]) = *reinterpret_cast<const uint32_t *>(&line_cr[mbx * 8 + j * 4]);
+            }
+            WAVE_SYNC();
+
+            // =====================================================================================
+            // chroma prediction (h264_intra_prediction.c:2157-2564 + transform4x4_chroma): lane j predicts chroma
+            // block j (plane j >> 2, block j & 3) -- all eight lanes of the octet
+            // =====================================================================================
+            {
+                const int pl = j >> 2, k = j & 3;
+                const int cx = (k & 1) * 4, cy = (k >> 1) * 4;
+                uint8_t *TCp = Q.TC[pl];
+                uint32_t pw[4] = {0u, 0u, 0u, 0u};
+                const uint32_t topw = *reinterpret_cast<const uint32_t *>(&TCp[8 + cx]);
+                const uint32_t lefw = *reinterpret_cast<const uint32_t *>(&Q.LcolC[pl][cy]);
+                if (cmode == 0) {
+                    const int bx = k & 1, by = k >> 1;
+                    const int sH = sum4(topw), sV = sum4(lefw);
+                    int v;
+                    if (!A && !Bv) v = 128;
+                    else if (bx == by) {
+                        if (A && Bv) v = (sH + sV + 4) >> 3;
+                        else if (A) v = (sV + 2) >> 2;
+                        else v = (sH + 2) >> 2;
+                    } else if (bx == 1) { // xO > 0, yO == 0: prefers top
+                        v = Bv ? ((sH + 2) >> 2) : ((sV + 2) >> 2);
+                    } else {              // xO == 0, yO > 0: prefers left
+                        v = A ? ((sV + 2) >> 2) : ((sH + 2) >> 2);
+                    }
+                    pw[0] = pw[1] = pw[2] = pw[3] = (uint32_t)v * 0x01010101u;
+                } else if (cmode == 1) {
+                    if (A) {
+#pragma unroll
+                        for (int y = 0; y < 4; y++) pw[y] = ((lefw >> (8 * y)) & 255u) * 0x01010101u;
+                    }
+                } else if (cmode == 2) {
+                    if (Bv) pw[0] = pw[1] = pw[2] = pw[3] = topw;
+                } else if (cmode == 3) {
+                    if (A && Bv) {
+                        const uint2 topv = *reinterpret_cast<const uint2 *>(&TCp[8]);
+                        const uint2 lefv = *reinterpret_cast<const uint2 *>(Q.LcolC[pl]);
+                        const int cor = TCp[7];
+                        const int Hh = plane_grad8(topv, (uint32_t)cor), Vv = plane_grad8(lefv, (uint32_t)cor);
+                        const int aa = 16 * ((int)(lefv.y >> 24) + (int)(topv.y >> 24));
+                        const int bb = (34 * Hh + 32) >> 6;
+                        const int cc = (34 * Vv + 32) >> 6;
+                        const int v00 = aa + bb * (cx - 3) + cc * (cy - 3) + 16;
+#pragma unroll
+                        for (int y = 0; y < 4; y++) pw[y] = plane_row(v00 + cc * y, bb);
+                    }
+                }
+                emit_block_ypairs(&TCp[(cy + 1) * 16 + 8 + cx], 16, pw, c2);
+            }
+
+            // =====================================================================================
+            // luma prediction
+            // =====================================================================================
+            if (kind == MVHP_KIND_I16x16) {
+                // h264_intra_prediction.c:1809-2141 + transform16x16_luma; lane j predicts its own two 4x4 blocks
+                uint32_t pw[2][4] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
+                if (i16mode == 0) {
+                    if (Bv) {
+                        const uint2 t = *reinterpret_cast<const uint2 *>(&Q.T[16 + xO0]);
+                        pw[0][0] = pw[0][1] = pw[0][2] = pw[0][3] = t.x;
+                        pw[1][0] = pw[1][1] = pw[1][2] = pw[1][3] = t.y;
+                    }
+                } else if (i16mode == 1) {
+                    if (A) {
+                        const uint32_t l = *reinterpret_cast<const uint32_t *>(&Q.Lcol[yO]);
+#pragma unroll
+                        for (int y = 0; y < 4; y++) pw[0][y] = pw[1][y] = ((l >> (8 * y)) & 255u) * 0x01010101u;
+                    }
+                } else if (i16mode == 2) {
+                    const uint4 topv = *reinterpret_cast<const uint4 *>(&Q.T[16]);
+                    const uint4 lefv = *reinterpret_cast<const uint4 *>(Q.Lcol);
+                    const int sumH = sum4(topv.x) + sum4(topv.y) + sum4(topv.z) + sum4(topv.w);
+                    const int sumV = sum4(lefv.x) + sum4(lefv.y) + sum4(lefv.z) + sum4(lefv.w);
+                    int v;
+                    if (A && Bv) v = (sumH + sumV + 16) >> 5;
+                    else if (A) v = (sumV + 8) >> 4;
+                    else if (Bv) v = (sumH + 8) >> 4;
+                    else v = 128;
+#pragma unroll
+                    for (int y = 0; y < 4; y++) pw[0][y] = pw[1][y] = (uint32_t)v * 0x01010101u;
+                } else if (i16mode == 3) {
+                    if (A && Bv) {
+                        const uint4 topv = *reinterpret_cast<const uint4 *>(&Q.T[16]);
+                        const uint4 lefv = *reinterpret_cast<const uint4 *>(Q.Lcol);
+                        const int cor = Q.T[15];
+                        const int Hh = plane_grad16(topv, (uint32_t)cor), Vv = plane_grad16(lefv, (uint32_t)cor);
+                        const int aa = 16 * ((int)(lefv.w >> 24) + (int)(topv.w >> 24));
+                        const int bb = (5 * Hh + 32) >> 6;
+                        const int cc = (5 * Vv + 32) >> 6;
+                        const int v00 = aa + bb * (xO0 - 7) + cc * (yO - 7) + 16;
+#pragma unroll
+                        for (int y = 0; y < 4; y++) {
+                            pw[0][y] = plane_row(v00 + cc * y, bb);
+                            pw[1][y] = plane_row(v00 + cc * y + 4 * bb, bb);
+                        }
+                    }
+                }
+                emit_block_ypairs(&Q.T[(yO + 1) * 32 + 16 + xO0], 32, pw[0], r2[0]);
+                emit_block_ypairs(&Q.T[(yO + 1) * 32 + 16 + xO0 + 4], 32, pw[1], r2[1]);
+            } else if (kind == MVHP_KIND_I4x4) {
+                // Intra 4x4: 16 dependent block steps; lane j predicts samples (j&3, j>>2) and (j&3, (j>>2)+2) of the block.
+                // h264_intra_prediction.c:161-177, :315-483, :496-960 + transform4x4_luma (h264_transform.c:121-156).
+                constexpr uint32_t X0 = (1u << 0) | (1u << 2) | (1u << 8) | (1u << 10);   // blocks with xO == 0
+                constexpr uint32_t Y0 = (1u << 0) | (1u << 1) | (1u << 4) | (1u << 5);    // blocks with yO == 0
+                const uint32_t av_left = A ? 0xffffu : (0xffffu & ~X0);
+                const uint32_t av_up = Bv ? 0xffffu : (0xffffu & ~Y0);
+                const uint32_t av_upleft = (0xffffu & ~(X0 | Y0)) | (Bv ? ((1u << 1) | (1u << 4) | (1u << 5)) : 0u) |
+                                           (A ? ((1u << 2) | (1u << 8) | (1u << 10)) : 0u) | (D ? 1u : 0u);
+                const uint32_t av_upright = ((1u << 2) | (1u << 6) | (1u << 8) | (1u << 9) | (1u << 10) | (1u << 12) | (1u << 14)) |
+                                            (Bv ? ((1u << 0) | (1u << 1) | (1u << 4)) : 0u) | (C ? (1u << 5) : 0u);
+                constexpr uint32_t REQ = (2u << 0) | (1u << 3) | (0u << 6) | (2u << 9) | (7u << 12) | (7u << 15) | (7u << 18) |
+                                         (2u << 21) | (1u << 24);
+                // control words of blocks 2j and 2j+1, computed by lane j and broadcast inside the octet at their steps:
+                // bit 31 the mode is DC, bit 3 prediction allowed, bits 8.. tap table row offset
+                uint32_t info[2];
+                const uint32_t mw = (j < 2) ? m0 : (j < 4) ? m1 : (j < 6) ? m2 : m3;
+#pragma unroll
+                for (int sl = 0; sl < 2; sl++) {
+                    const int b = 2 * j + sl;
+                    const uint32_t mode = (mw >> ((b & 3) * 8)) & 255u;
+                    const uint32_t avail = ((av_left >> b) & 1u) | (((av_up >> b) & 1u) << 1) | (((av_upleft >> b) & 1u) << 2);
+                    const uint32_t req = (REQ >> (min(mode, 8u) * 3)) & 7u;
+                    const uint32_t ok = (((req & ~avail) == 0u) && (mode < 9u)) ? 1u : 0u; // else the prediction stays 0 (:442)
+                    const uint32_t trow = (((av_upright >> b) & 1u) ? 0u : 9u) + min(mode, 8u);
+                    info[sl] = ((mode == 2u) ? 0x80000000u : 0u) | (ok << 3) | ((trow * 64u) << 8);
+                }
+                const int pix = (j >> 2) * 32 + (j & 3);   // the lane's upper sample inside a block, tile units (lower: +64)
+                const uint8_t *T = Q.T;
+                const uint8_t *tapb = reinterpret_cast<const uint8_t *>(B.tap4) + j * 4;
+                const int32_t *res32 = reinterpret_cast<const int32_t *>(Q.res) + j;
+                // software pipeline: control word, table entries and residuals of block b+1 are fetched before block
+                // b's dependent tile reads
+                uint32_t inf = (uint32_t)__builtin_amdgcn_ds_bpermute(obase4, (int)info[0]);
+                uint32_t ea_nx = *reinterpret_cast<const uint32_t *>(tapb + ((inf >> 8) & 0xffffu));
+                uint32_t eb_nx = *reinterpret_cast<const uint32_t *>(tapb + ((inf >> 8) & 0xffffu) + 32);
+                int r_nx = res32[0];
+#pragma unroll
+                for (int blk = 0; blk < 16; blk++) {
+                    const int bxO = (((blk >> 2) & 1) << 3) | ((blk & 1) << 2);
+                    const int byO = ((blk >> 3) << 3) | (((blk >> 1) & 1) << 2);
+                    const int base = (byO + 1) * 32 + 16 + bxO;     // tile index of the block's top-left sample
+                    const uint32_t cur = inf;
+                    const uint32_t ea = ea_nx, eb = eb_nx;
+                    const int r = r_nx;
+                    if (blk < 15) {
+                        inf = (uint32_t)__builtin_amdgcn_ds_bpermute(obase4 + ((blk + 1) >> 1) * 4, (int)info[(blk + 1) & 1]);
+                        ea_nx = *reinterpret_cast<const uint32_t *>(tapb + ((inf >> 8) & 0xffffu));
+                        eb_nx = *reinterpret_cast<const uint32_t *>(tapb + ((inf >> 8) & 0xffffu) + 32);
+                        r_nx = res32[(blk + 1) * 8];
+                    }
+                    const int okmask = ((int)(cur << 28)) >> 31;   // bit 3 -> 0 / -1
+                    const int a0 = T[base - 33 + (int)(ea & 255)], b0 = T[base - 33 + (int)((ea >> 8) & 255)], c0 = T[base - 33 + (int)(ea >> 16)];
+                    const int a1 = T[base - 33 + (int)(eb & 255)], b1 = T[base - 33 + (int)((eb >> 8) & 255)], c1 = T[base - 33 + (int)(eb >> 16)];
+                    int p0 = ((a0 + 2 * b0 + c0 + 2) >> 2) & okmask;
+                    int p1 = ((a1 + 2 * b1 + c1 + 2) >> 2) & okmask;
+                    const bool isdc = (int)cur < 0;
+                    if (__builtin_amdgcn_ballot_w64(isdc) != 0) { // some picture predicts DC
+                        // which neighbours exist is positional, i.e. the same for the eight pictures: scalar branches
+                        const bool bl = (bxO > 0) || A, bu = (byO > 0) || Bv;
+                        int dcv = 128;
+                        if (bl && bu) {
+                            const int sumH = sum4(*reinterpret_cast<const uint32_t *>(&T[base - 32]));
+                            const int sumV = T[base - 1] + T[base + 31] + T[base + 63] + T[base + 95];
+                            dcv = (sumH + sumV + 4) >> 3;
+                        } else if (bl) {
+                            dcv = (T[base - 1] + T[base + 31] + T[base + 63] + T[base + 95] + 2) >> 2;
+                        } else if (bu) {
+                            dcv = (sum4(*reinterpret_cast<const uint32_t *>(&T[base - 32])) + 2) >> 2;
+                        }
+                        p0 = isdc ? dcv : p0;
+                        p1 = isdc ? dcv : p1;
+                    }
+                    const uint32_t two = sat_pk_u8(pk_add_sat(p0 | (p1 << 16), r));   // byte 0: upper sample, byte 1: lower
+                    Q.T[base + pix] = (uint8_t)two;
+                    Q.T[base + pix + 64] = (uint8_t)(two >> 8);
+                    WAVE_SYNC();
+                }
+            } else {
+                // Intra 8x8: h264_intra_prediction.c:1107-1353 (edge filter) + :1366-1793 + transform8x8_luma;
+                // lane j predicts row j of the block
+#pragma unroll 1
+                for (int blk = 0; blk < 4; blk++) {
+                    const int bxO = (blk & 1) * 8, byO = (blk >> 1) * 8;
+                    const int mode = (int)((m0 >> (blk * 8)) & 255u);
+                    const bool left = (bxO > 0) || A;
+                    const bool up = (byO > 0) || Bv;
+                    const bool upleft = (bxO > 0) ? ((byO > 0) || Bv) : ((byO > 0) ? A : D);
+                    const bool upright = (blk == 0) ? Bv : (blk == 1) ? C : (blk == 2);
+                    const uint8_t *Trow = &Q.T[byO * 32 + 16 + bxO];
+                    const uint8_t *Tcol = &Q.T[(byO + 1) * 32 + 15 + bxO];
+#pragma unroll
+                    for (int part = 0; part < 4; part++) {
+                        const int el = j + 8 * part;
+                        if (el < 28) {
+                            // raw edge sample for EE8 index e: e<=9: left[9-e] (clamped), 10: corner, >=11: top[e-11]
+                            const int e = min(max(el, 2), 26);
+                            const int maxi = upright ? 15 : 7;
+                            int lo = e - 1, hi = e + 1;
+                            if (e == 2 || (e == 11 && !upleft) || (e == 10 && !left)) lo = e;
+                            if (e == 26 || (e == 9 && !upleft) || (e == 10 && !up)) hi = e;
+                            int v[3];
+                            const int idxs[3] = {lo, e, hi};
+#pragma unroll
+                            for (int t = 0; t < 3; t++) {
+                                const int idx = idxs[t];
+                                v[t] = (idx >= 10) ? (int)Trow[min(idx - 11, maxi)] : (int)Tcol[(9 - idx) * 32];
+                            }
+                            Q.E8[el] = (uint8_t)((v[0] + 2 * v[1] + v[2] + 2) >> 2);
+                        }
+                    }
+                    WAVE_SYNC();
+                    {
+                        const int y = j;
+                        uint32_t pwa = 0, pwb = 0;   // samples 0..3 and 4..7 of the row
+                        if (mode == 2) {
+                            const uint32_t *E = reinterpret_cast<const uint32_t *>(Q.E8);
+                            const uint32_t w0 = E[0], w1 = E[1], w2 = E[2], w3 = E[3], w4 = E[4];
+                            const int sumV = sum4(w0 & 0xffff0000u) + sum4(w1) + sum4(w2 & 0x0000ffffu);       // E8[2..9]
+                            const int sumH = sum4(w2 & 0xff000000u) + sum4(w3) + sum4(w4 & 0x00ffffffu);       // E8[11..18]
+                            int v;
+                            if (left && up) v = (sumH + sumV + 8) >> 4;
+                            else if (left) v = (sumV + 4) >> 3;
+                            else if (up) v = (sumH + 4) >> 3;
+                            else v = 128;
+                            pwa = pwb = (uint32_t)v * 0x01010101u;
+                        } else {
+                            bool ok;
+                            switch (mode) {
+                            case 0: case 3: case 7: ok = up; break;
+                            case 1: case 8: ok = left; break;
+                            default: ok = left && up && upleft; break;
+                            }
+                            if (ok && mode < 9) {
+                                const uint4 e4a = *reinterpret_cast<const uint4 *>(&B.tap8[mode * 64 + y * 8]);
+                                const uint4 e4b = *reinterpret_cast<const uint4 *>(&B.tap8[mode * 64 + y * 8 + 4]);
+                                const uint32_t ee[8] = {e4a.x, e4a.y, e4a.z, e4a.w, e4b.x, e4b.y, e4b.z, e4b.w};
+#pragma unroll
+                                for (int x = 0; x < 8; x++) {
+                                    const int v0 = Q.E8[ee[x] & 255], v1 = Q.E8[(ee[x] >> 8) & 255], v2 = Q.E8[ee[x] >> 16];
+                                    const uint32_t pv = (uint32_t)((v0 + 2 * v1 + v2 + 2) >> 2) << (8 * (x & 3));
+                                    if (x < 4) pwa |= pv; else pwb |= pv;
+                                }
+                            }
+                        }
+                        int4 rr = make_int4(0, 0, 0, 0);
+                        if (need_l) rr = *reinterpret_cast<const int4 *>(&Q.res[blk * 64 + y * 8]);
+                        const uint32_t oa = sat_pk_u8(pk_add_sat((int)__builtin_amdgcn_perm(0u, pwa, 0x0c010c00u), rr.x)) |
+                                            (sat_pk_u8(pk_add_sat((int)__builtin_amdgcn_perm(0u, pwa, 0x0c030c02u), rr.y)) << 16);
+                        const uint32_t ob = sat_pk_u8(pk_add_sat((int)__builtin_amdgcn_perm(0u, pwb, 0x0c010c00u), rr.z)) |
+                                            (sat_pk_u8(pk_add_sat((int)__builtin_amdgcn_perm(0u, pwb, 0x0c030c02u), rr.w)) << 16);
+                        *reinterpret_cast<uint2 *>(&Q.T[(byO + y + 1) * 32 + 16 + bxO]) = make_uint2(oa, ob);
+                    }
+                    WAVE_SYNC();
+                }
+            }
+            WAVE_SYNC();
+
+            // =====================================================================================
+            // write-out (mb_to_rgb, export_utils.c:209-324, fused): lane j holds luma rows j, j+8 and chroma row j of
+            // both planes; park, or flush the 4-macroblock strip
+            // =====================================================================================
+            {
+                const int mbi = mbx & 3;
+                const uint4 ya = *reinterpret_cast<const uint4 *>(&Q.T[(j + 1) * 32 + 16]);
+                const uint4 yb = *reinterpret_cast<const uint4 *>(&Q.T[(j + 9) * 32 + 16]);
+                const uint2 cvb = *reinterpret_cast<const uint2 *>(&Q.TC[0][(j + 1) * 16 + 8]);
+                const uint2 cvr = *reinterpret_cast<const uint2 *>(&Q.TC[1][(j + 1) * 16 + 8]);
+                uint2 cba = make_uint2(0u, 0u), cra = cba, cbb = cba, crb = cba;   // chroma rows of luma rows j / j+8
+                if (RGB) {
+                    cba = *reinterpret_cast<const uint2 *>(&Q.TC[0][((j >> 1) + 1) * 16 + 8]);
+                    cra = *reinterpret_cast<const uint2 *>(&Q.TC[1][((j >> 1) + 1) * 16 + 8]);
+                    cbb = *reinterpret_cast<const uint2 *>(&Q.TC[0][((j >> 1) + 5) * 16 + 8]);
+                    crb = *reinterpret_cast<const uint2 *>(&Q.TC[1][((j >> 1) + 5) * 16 + 8]);
+                }
+                const v4i yqa = {(int)ya.x, (int)ya.y, (int)ya.z, (int)ya.w}, yqb = {(int)yb.x, (int)yb.y, (int)yb.z, (int)yb.w};
+                n_st = 0;
+                if (mbi == 3 || mbx == W - 1) {
+                    uint32_t qmb_v = qmb;
+                    asm volatile("" : "+v"(qmb_v));
+                    const uint32_t oyuv = OYUV;
+                    const uint32_t lrow = (uint32_t)((row * 16 + j) * pitch + (mbx & ~3) * 16);   // luma row j, inside the plane
+                    const uint32_t pya = oyuv + lrow, pyb = pya + 8 * pitch;
+                    const uint32_t pcb = oyuv + plane_y + (uint32_t)((row * 8 + j) * cpitch + (mbx & ~3) * 8), pcr = pcb + plane_c;
+                    const uint32_t prgba = ORGB + lrow * 3u, prgbb = prgba + 24 * pitch;
+                    const uint2 *ownb = reinterpret_cast<const uint2 *>(&Q.SC[0][j * 24]);   // parked: this lane's chroma rows
+                    const uint2 *ownr = reinterpret_cast<const uint2 *>(&Q.SC[1][j * 24]);
+                    const uint2 *pba = reinterpret_cast<const uint2 *>(&Q.SC[0][(j >> 1) * 24]);        // parked: rows for RGB
+                    const uint2 *pra = reinterpret_cast<const uint2 *>(&Q.SC[1][(j >> 1) * 24]);
+                    const uint2 *pbb = reinterpret_cast<const uint2 *>(&Q.SC[0][((j >> 1) + 4) * 24]);
+                    const uint2 *prb = reinterpret_cast<const uint2 *>(&Q.SC[1][((j >> 1) + 4) * 24]);
+                    if (mbi == 3) {
+                        // ---- full strip: exactly VM_STRIP store instructions ----
+                        const uint2 b0 = ownb[0], b1 = ownb[1], b2 = ownb[2], q0 = ownr[0], q1 = ownr[1], q2 = ownr[2];
+                        const v4i cb01 = {(int)b0.x, (int)b0.y, (int)b1.x, (int)b1.y}, cb23 = {(int)b2.x, (int)b2.y, (int)cvb.x, (int)cvb.y};
+                        const v4i cr01 = {(int)q0.x, (int)q0.y, (int)q1.x, (int)q1.y}, cr23 = {(int)q2.x, (int)q2.y, (int)cvr.x, (int)cvr.y};
+#define MVHP_ST(ADDR, DATA, BASE, OFF) asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 offset:" #OFF "\n\ts_nop 1" : : "v"(ADDR), "v"(DATA), "s"(BASE) : "memory")
+                        if (valid) {
+                            MVHP_ST(pya, st_a0, gyuv, 0); MVHP_ST(pya, st_a1, gyuv, 16); MVHP_ST(pya, st_a2, gyuv, 32); MVHP_ST(pya, yqa, gyuv, 48);
+                            MVHP_ST(pyb, st_b0, gyuv, 0); MVHP_ST(pyb, st_b1, gyuv, 16); MVHP_ST(pyb, st_b2, gyuv, 32); MVHP_ST(pyb, yqb, gyuv, 48);
+                            MVHP_ST(pcb, cb01, gyuv, 0); MVHP_ST(pcb, cb23, gyuv, 16);
+                            MVHP_ST(pcr, cr01, gyuv, 0); MVHP_ST(pcr, cr23, gyuv, 16);
+                        }
+                        if (RGB) {
+#if defined(MVHP_ABL_NO_RGB_STORE)
+#define MVHP_RGB_STORE_COND false
+#else
+#define MVHP_RGB_STORE_COND valid
+#endif
+#define MVHP_RGB_OUT(ADDR, YQ, CB, CR, OFF)                                                                            \
+                            {                                                                                          \
+                                v4i a0, a1, a2;                                                                        \
+                                const uint4 yy = make_uint4((uint32_t)(YQ).x, (uint32_t)(YQ).y, (uint32_t)(YQ).z, (uint32_t)(YQ).w); \
+                                rgb16(yy, CB, CR, a0, a1, a2);                                                         \
+                                if (MVHP_RGB_STORE_COND) {                                                             \
+                                    MVHP_ST(ADDR, a0, grgb, OFF); MVHP_ST(ADDR, a1, grgb, OFF + 16); MVHP_ST(ADDR, a2, grgb, OFF + 32); \
+                                } else {                                                                               \
+                                    asm volatile("" : : "v"(a0), "v"(a1), "v"(a2));                                    \
+                                }                                                                                      \
+                            }
+                            MVHP_RGB_OUT(prgba, st_a0, pba[0], pra[0], 0)
+                            MVHP_RGB_OUT(prgba, st_a1, pba[1], pra[1], 48)
+                            MVHP_RGB_OUT(prgba, st_a2, pba[2], pra[2], 96)
+                            MVHP_RGB_OUT(prgba, yqa, cba, cra, 144)
+                            MVHP_RGB_OUT(prgbb, st_b0, pbb[0], prb[0], 0)
+                            MVHP_RGB_OUT(prgbb, st_b1, pbb[1], prb[1], 48)
+                            MVHP_RGB_OUT(prgbb, st_b2, pbb[2], prb[2], 96)
+                            MVHP_RGB_OUT(prgbb, yqb, cbb, crb, 144)
+#undef MVHP_RGB_OUT
+#undef MVHP_RGB_STORE_COND
+                        }
+#undef MVHP_ST
+                        n_st = VM_STRIP;
+                    } else {
+                        // ---- short strip at the right picture edge (W % 4 != 0): compiler-counted stores ----
+#pragma unroll
+                        for (int k = 0; k < 3; k++) {
+                            if (k > mbi) continue;
+                            const bool last = (k == mbi);
+                            const v4i yka = last ? yqa : (k == 0 ? st_a0 : st_a1), ykb = last ? yqb : (k == 0 ? st_b0 : st_b1);
+                            const uint2 ob = ownb[k], orr = ownr[k], xba = pba[k], xra = pra[k], xbb = pbb[k], xrb = prb[k];   // read first, then choose values
+                            uint2 ckb, ckr, kba, kra, kbb, krb;
+                            ckb.x = last ? cvb.x : ob.x; ckb.y = last ? cvb.y : ob.y;
+                            ckr.x = last ? cvr.x : orr.x; ckr.y = last ? cvr.y : orr.y;
+                            kba.x = last ? cba.x : xba.x; kba.y = last ? cba.y : xba.y;
+                            kra.x = last ? cra.x : xra.x; kra.y = last ? cra.y : xra.y;
+                            kbb.x = last ? cbb.x : xbb.x; kbb.y = last ? cbb.y : xbb.y;
+                            krb.x = last ? crb.x : xrb.x; krb.y = last ? crb.y : xrb.y;
+                            if (valid) {
+                                *reinterpret_cast<v4i *>(gyuv + pya + k * 16) = yka;
+                                *reinterpret_cast<v4i *>(gyuv + pyb + k * 16) = ykb;
+                                *reinterpret_cast<uint2 *>(gyuv + pcb + k * 8) = ckb;
+                                *reinterpret_cast<uint2 *>(gyuv + pcr + k * 8) = ckr;
+                            }
+                            if (RGB) {
+                                v4i a0, a1, a2;
+                                rgb16(make_uint4((uint32_t)yka.x, (uint32_t)yka.y, (uint32_t)yka.z, (uint32_t)yka.w), kba, kra, a0, a1, a2);
+                                if (valid) {
+                                    v4i *dst = reinterpret_cast<v4i *>(grgb + prgba + k * 48);
+                                    dst[0] = a0; dst[1] = a1; dst[2] = a2;
+                                }
+                                rgb16(make_uint4((uint32_t)ykb.x, (uint32_t)ykb.y, (uint32_t)ykb.z, (uint32_t)ykb.w), kbb, krb, a0, a1, a2);
+                                if (valid) {
+                                    v4i *dst = reinterpret_cast<v4i *>(grgb + prgbb + k * 48);
+                                    dst[0] = a0; dst[1] = a1; dst[2] = a2;
+                                }
+                            }
+                        }
+                    }
+                } else {
+                    // ---- park: luma rows in registers, chroma rows in the LDS strip ----
+                    *reinterpret_cast<uint2 *>(&Q.SC[0][j * 24 + mbi * 8]) = cvb;
+                    *reinterpret_cast<uint2 *>(&Q.SC[1][j * 24 + mbi * 8]) = cvr;
+                    if (mbi == 0) { st_a0 = yqa; st_b0 = yqb; }
+                    else if (mbi == 1) { st_a1 = yqa; st_b1 = yqb; }
+                    else { st_a2 = yqa; st_b2 = yqb; }
+                }
+            }
+
+            // =====================================================================================
+            // neighbour state for the next macroblock / next row, then publish
+            // =====================================================================================
+            {
+                // left columns: lane j luma rows j, j+8 and chroma row j of both planes; corners (old top-right sample) by
+                // lanes 0-2; bottom rows -> line buffer: lanes 0-3 luma, 4-5 Cb, 6-7 Cr (one dword each)
+                const uint8_t kla = Q.T[(j + 1) * 32 + 31], klb = Q.T[(j + 9) * 32 + 31];
+                const uint8_t kcb = Q.TC[0][(j + 1) * 16 + 15], kcr = Q.TC[1][(j + 1) * 16 + 15];
+                uint8_t kk = 0;
+                uint8_t *kdst = &Q.T[15];
+                if (j == 0) kk = Q.T[31];
+                else if (j == 1) { kk = Q.TC[0][15]; kdst = &Q.TC[0][7]; }
+                else if (j == 2) { kk = Q.TC[1][15]; kdst = &Q.TC[1][7]; }
+                uint32_t bot;
+                uint8_t *bdst;
+                if (j < 4) { bot = *reinterpret_cast<const uint32_t *>(&Q.T[16 * 32 + 16 + j * 4]); bdst = &line_y[mbx * 16 + j * 4]; }
+                else if (j < 6) { bot = *reinterpret_cast<const uint32_t *>(&Q.TC[0][8 * 16 + 8 + (j - 4) * 4]); bdst = &line_cb[mbx * 8 + (j - 4) * 4]; }
+                else { bot = *reinterpret_cast<const uint32_t *>(&Q.TC[1][8 * 16 + 8 + (j - 6) * 4]); bdst = &line_cr[mbx * 8 + (j - 6) * 4]; }
+                WAVE_SYNC();
+                Q.T[(j + 1) * 32 + 15] = kla;
+                Q.T[(j + 9) * 32 + 15] = klb;
+                Q.Lcol[j] = kla;
+                Q.Lcol[j + 8] = klb;
+                Q.TC[0][(j + 1) * 16 + 7] = kcb;
+                Q.TC[1][(j + 1) * 16 + 7] = kcr;
+                Q.LcolC[0][j] = kcb;
+                Q.LcolC[1][j] = kcr;
+                if (j < 3) *kdst = kk;
+                *reinterpret_cast<uint32_t *>(bdst) = bot;
+            }
+            done++;
+            // LDS operations of one wave complete in order; the explicit wait makes the line-buffer
+            // writes land before the counter without waiting for the global plane stores (vmcnt).
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (lane == 0) __hip_atomic_store(&B.progress[wave], done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            WAVE_SYNC();
+        }
+    }
+}
+
+#undef OPACKED
+#undef OYUV
+#undef ORGB
+
+size_t recon_oct_lds_bytes(int width_mbs, int nw)
+{
+    return sizeof(QTables) + (size_t)8 * width_mbs * 32 + (size_t)nw * 8 * sizeof(QLds);
+}
+
+template <int NW, bool RGB>
+static hipError_t launch_oct_one(const ReconArgs &a, hipStream_t stream)
+{
+    const size_t lds = recon_oct_lds_bytes(a.width_mbs, NW);
+    const int groups = (a.n_frames + 7) / 8;
+    hipError_t e = hipFuncSetAttribute((const void *)recon_oct_kernel<NW, RGB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((recon_oct_kernel<NW, RGB>), dim3(groups), dim3(NW * 64), lds, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_recon_oct(const ReconArgs &a, int nw, hipStream_t stream)
+{
+    const bool rgb = a.rgb != nullptr;
+    switch (nw) {
+    case 4: return rgb ? launch_oct_one<4, true>(a, stream) : launch_oct_one<4, false>(a, stream);
+    case 6: return rgb ? launch_oct_one<6, true>(a, stream) : launch_oct_one<6, false>(a, stream);
+    case 8: return rgb ? launch_oct_one<8, true>(a, stream) : launch_oct_one<8, false>(a, stream);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+} // namespace mvhp

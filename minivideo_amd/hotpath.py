@@ -134,9 +134,9 @@ class HotPath:
 
     def set_layout(self, layout):
         """0 auto, 1 one picture per workgroup (rows), 2 four pictures per workgroup (quad); speed only."""
-        code = {"auto": 0, "rows": 1, "quad": 2}.get(layout, layout)
+        code = {"auto": 0, "rows": 1, "quad": 2, "oct": 3}.get(layout, layout)
         if self._L.mvhp_set_layout(self._h, int(code)) != SUCCESS:
-            raise ValueError("layout must be auto/rows/quad")
+            raise ValueError("layout must be auto/rows/quad/oct")
 
     def set_fused_color(self, on):
         self._L.mvhp_set_fused_color(self._h, 1 if on else 0)

@@ -14,8 +14,13 @@ HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
 def test_quad_prefetch_registers_untouched_and_store_count(tmp_path):
-    out = tmp_path / "recon_quad.s"
-    src = os.path.join(ROOT, "minivideo_amd", "csrc", "hip", "recon_quad.hip")
+    _check_one(tmp_path, "recon_quad")
+    _check_one(tmp_path, "recon_oct")
+
+
+def _check_one(tmp_path, name):
+    out = tmp_path / (name + ".s")
+    src = os.path.join(ROOT, "minivideo_amd", "csrc", "hip", name + ".hip")
     r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-I" + os.path.join(ROOT, "include"),
                         "-I" + os.path.dirname(src), src, "--cuda-device-only", "-S", "-o", str(out)],
                        capture_output=True, text=True, timeout=300)

@@ -18,11 +18,18 @@ def regs(tok):
     return out
 
 
-PREFETCH = set(range(100, 124))
+# kernel family -> (prefetch registers, asm loads per prefetch block, stores of a full strip without / with RGB)
+FAMILIES = {
+    "recon_quad_kernel": (set(range(100, 124)), 6, (6, 18)),
+    "recon_oct_kernel": (set(range(216, 248)), 8, (12, 36)),
+}
 
 
 def check(L, name):
     """L = the lines of one kernel."""
+    fam = next(v for k, v in FAMILIES.items() if k in name)
+    PREFETCH, n_block, strip_counts = fam
+    first = "v[%d:%d]" % (min(PREFETCH), min(PREFETCH) + 1)
     in_asm, touched, asm_loads, asm_stores_at = False, [], [], []
     for i, raw in enumerate(L):
         if '#ASMSTART' in raw:
@@ -43,12 +50,12 @@ def check(L, name):
                 assert not (regs(l) & PREFETCH), (name, l)
         elif regs(l) & PREFETCH:
             touched.append((i, l))
-    assert len(asm_loads) == 12, (name, len(asm_loads))      # 6 in the prologue + 6 in the loop
-    # the guarded waits: asm blocks that start with s_waitcnt vmcnt(N) and then move v100.. out
-    waits = [i for i, l in enumerate(L) if re.search(r's_waitcnt vmcnt\(\d+\)', l) and 'v[100:101]' in L[i + 1]]
+    assert len(asm_loads) == 2 * n_block, (name, len(asm_loads))      # one block in the prologue, one in the loop
+    # the guarded waits: asm blocks that start with s_waitcnt vmcnt(N) and then move the prefetch registers out
+    waits = [i for i, l in enumerate(L) if re.search(r's_waitcnt vmcnt\(\d+\)', l) and first in L[i + 1]]
     assert len(waits) == 2, (name, waits)
     counts = sorted(int(re.search(r'vmcnt\((\d+)\)', L[w]).group(1)) for w in waits)
-    assert counts[0] == 0 and counts[1] in (6, 18), (name, counts)
+    assert counts[0] == 0 and counts[1] in strip_counts, (name, counts)
     n_expect = counts[1]
     w0 = min(waits)
     # the macroblock loop: the nearest label above the waits that a later instruction branches back to
@@ -66,7 +73,7 @@ def check(L, name):
     #     the waits -- the compiler must not use v100-v123 (it may use them as scratch registers between a wait and
     #     the next load block: the record has been moved out, the loads are not issued yet)
     loop_loads = [i for i in asm_loads if i > max(waits)]
-    assert len(loop_loads) == 6, (name, loop_loads)
+    assert len(loop_loads) == n_block, (name, loop_loads)
     bad = [(i, l) for i, l in touched if loop_loads[0] <= i <= max(back) or labi <= i <= max(waits)]
     assert not bad, (name, 'compiler code touches the prefetch registers while loads are in flight', bad[:5])
     pro = [i for i in asm_loads if i < labi]
@@ -81,7 +88,7 @@ def check(L, name):
 
 def main(path):
     text = open(path).read().split('\n')
-    starts = [i for i, l in enumerate(text) if re.match(r'^_ZN4mvhp17recon_quad_kernel\S+:', l)]
+    starts = [i for i, l in enumerate(text) if re.match(r'^_ZN4mvhp\d+recon_(quad|oct)_kernel\S+:', l)]
     assert starts
     for s in starts:
         e = next(i for i in range(s, len(text)) if 's_endpgm' in text[i])
