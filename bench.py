@@ -159,8 +159,9 @@ def main():
     hot.set_layout(args.layout)
     # which reconstruction kernel the library picks (mirrors pick_quad() in hotpath_abi.hip: speed only)
     n_cus = torch.cuda.get_device_properties(dev).multi_processor_count
-    quad = args.layout == "quad" or (args.layout == "auto" and F >= 3 * n_cus)
-    recon_name = "recon_oct_kernel" if args.layout == "oct" else ("recon_quad_kernel" if quad else "recon_rows_kernel")
+    octl = args.layout == "oct" or (args.layout == "auto" and F >= 8 * n_cus)
+    quad = not octl and (args.layout == "quad" or (args.layout == "auto" and F >= 3 * n_cus))
+    recon_name = "recon_oct_kernel" if octl else ("recon_quad_kernel" if quad else "recon_rows_kernel")
     fused = want_rgb and not args.no_fused
     hot.set_fused_color(fused)
     # a dedicated (non-null) stream: the C-ABI treats a NULL stream as "the context's own stream",
@@ -255,7 +256,8 @@ def main():
                 "frames_per_gpu_per_step": F,
                 "macroblocks_per_step": world * mbs_per_step,
                 "stages": "dequant+IDCT+intra prediction+reconstruct -> planar YCbCr" + (" -> RGB" if want_rgb else ""),
-                "parallelism": (("four pictures per workgroup (16 lanes per picture)" if quad else "one picture per workgroup")
+                "parallelism": (("eight pictures per workgroup (8 lanes per picture)" if octl else
+                                 "four pictures per workgroup (16 lanes per picture)" if quad else "one picture per workgroup")
                                 + f", pictures sharded over {world} GPU(s), no collectives"),
                 "bit_exact_vs_oracle": ok,
             },

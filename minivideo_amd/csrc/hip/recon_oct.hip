@@ -81,7 +81,9 @@ __global__ __launch_bounds__(NW * 64) void recon_oct_kernel(ReconArgs a)
 
     // Record prefetch, one macroblock ahead, in v216-v247: header (32 B), the lane's two luma blocks (64 B), its
     // chroma block (32 B).  A step issues no store or exactly VM_STRIP stores behind the eight loads (`n_st`).
-#if defined(MVHP_ABL_NO_RGB_STORE)
+#if defined(MVHP_ABL_NO_YUV_STORE)
+    constexpr int VM_STRIP = 0;
+#elif defined(MVHP_ABL_NO_RGB_STORE)
     constexpr int VM_STRIP = 12;
 #else
     constexpr int VM_STRIP = RGB ? 36 : 12;   // a full strip: 2 rows x 4 luma + 2 x 2 chroma (+ 2 x 12 RGB) 16-byte stores
@@ -90,7 +92,11 @@ __global__ __launch_bounds__(NW * 64) void recon_oct_kernel(ReconArgs a)
         const int jj = lane_p & 7;
         uint32_t qmb_v = qmb;
         asm volatile("" : "+v"(qmb_v));
+#if defined(MVHP_ABL_SAME_RECORD)
+        const uint32_t rec = OPACKED + (uint32_t)((prow & 1) * W + (px & 7)) * MVHP_MB_BYTES;   // measurement build: cache-resident input
+#else
         const uint32_t rec = OPACKED + (uint32_t)(prow * W + px) * MVHP_MB_BYTES;
+#endif
         const uint32_t recL = rec + MVHP_MB_HEADER_BYTES + jj * 64;
         const uint32_t recC = rec + MVHP_MB_HEADER_BYTES + (16 + jj) * 32;
         asm volatile("s_nop 4\n\t"
@@ -669,7 +675,11 @@ __global__ __launch_bounds__(NW * 64) void recon_oct_kernel(ReconArgs a)
                         const v4i cb01 = {(int)b0.x, (int)b0.y, (int)b1.x, (int)b1.y}, cb23 = {(int)b2.x, (int)b2.y, (int)cvb.x, (int)cvb.y};
                         const v4i cr01 = {(int)q0.x, (int)q0.y, (int)q1.x, (int)q1.y}, cr23 = {(int)q2.x, (int)q2.y, (int)cvr.x, (int)cvr.y};
 #define MVHP_ST(ADDR, DATA, BASE, OFF) asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 offset:" #OFF "\n\ts_nop 1" : : "v"(ADDR), "v"(DATA), "s"(BASE) : "memory")
+#if defined(MVHP_ABL_NO_YUV_STORE)
+                        if (valid && a.n_frames < 0) {
+#else
                         if (valid) {
+#endif
                             MVHP_ST(pya, st_a0, gyuv, 0); MVHP_ST(pya, st_a1, gyuv, 16); MVHP_ST(pya, st_a2, gyuv, 32); MVHP_ST(pya, yqa, gyuv, 48);
                             MVHP_ST(pyb, st_b0, gyuv, 0); MVHP_ST(pyb, st_b1, gyuv, 16); MVHP_ST(pyb, st_b2, gyuv, 32); MVHP_ST(pyb, yqb, gyuv, 48);
                             MVHP_ST(pcb, cb01, gyuv, 0); MVHP_ST(pcb, cb23, gyuv, 16);

@@ -16,6 +16,8 @@ for f in glob.glob(os.path.join(out, "pass*", "**", "*counter_collection.csv"), 
             k = "recon_rows_kernel"
         elif "recon_quad" in k:
             k = "recon_quad_kernel"
+        elif "recon_oct" in k:
+            k = "recon_oct_kernel"
         elif "ycbcr_to_rgb" in k:
             k = "ycbcr_to_rgb_kernel"
         else:
