@@ -25,6 +25,10 @@
 
 namespace mvhp {
 
+#ifndef MVHP_CHAIN_PRIO
+#define MVHP_CHAIN_PRIO 2   // wave priority inside the Intra4x4 chain (measured: 0 -> 2 = -2 % / -6 % kernel time with / without RGB)
+#endif
+
 // The compiler is left to the low registers (256 are available at two waves per SIMD; it needs ~190); v216-v247 are
 // the record prefetch registers, named only inside inline assembly (see recon_quad.hip and
 // tools/check_prefetch_hazard.py, which checks the ISA of every instantiation).
@@ -511,6 +515,7 @@ __global__ __launch_bounds__(NW * 64) void recon_oct_kernel(ReconArgs a)
                 const int32_t *res32 = reinterpret_cast<const int32_t *>(Q.res) + j;
                 // software pipeline: control word, table entries and residuals of block b+1 are fetched before block
                 // b's dependent tile reads
+                __builtin_amdgcn_s_setprio(MVHP_CHAIN_PRIO);   // the dependent chain issues few, latency-critical instructions
                 uint32_t inf = (uint32_t)__builtin_amdgcn_ds_bpermute(obase4, (int)info[0]);
                 uint32_t ea_nx = *reinterpret_cast<const uint32_t *>(tapb + ((inf >> 8) & 0xffffu));
                 uint32_t eb_nx = *reinterpret_cast<const uint32_t *>(tapb + ((inf >> 8) & 0xffffu) + 32);
@@ -556,6 +561,7 @@ __global__ __launch_bounds__(NW * 64) void recon_oct_kernel(ReconArgs a)
                     Q.T[base + pix + 64] = (uint8_t)(two >> 8);
                     WAVE_SYNC();
                 }
+                __builtin_amdgcn_s_setprio(0);
             } else {
                 // Intra 8x8: h264_intra_prediction.c:1107-1353 (edge filter) + :1366-1793 + transform8x8_luma;
                 // lane j predicts row j of the block

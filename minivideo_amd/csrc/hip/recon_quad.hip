@@ -29,6 +29,10 @@
 
 namespace mvhp {
 
+#ifndef MVHP_CHAIN_PRIO
+#define MVHP_CHAIN_PRIO 2   // wave priority inside the Intra4x4 chain
+#endif
+
 // 128 VGPRs = four waves per SIMD: two 8-wave workgroups (or four 4-wave ones) per CU; LDS allows as many.
 // The compiler gets v0-v99 (plus one register above everything for its SGPR spill lanes); v100-v123 are the
 // record prefetch registers, named only inside inline assembly, so
@@ -509,6 +513,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_num_vgpr(100))) void
                 // software pipeline: control word, table entry and residual of block b+1 are fetched before block
                 // b's dependent tile reads (the residual array holds zeros when the macroblock has none)
                 const int qbase4 = (lane & 48) << 2;
+                __builtin_amdgcn_s_setprio(MVHP_CHAIN_PRIO);   // the dependent chain issues few, latency-critical instructions
                 uint32_t inf = quarter_bcast(info, qbase4, 0);
                 uint32_t e_nx = *reinterpret_cast<const uint32_t *>(tapb + ((inf >> 8) & 0xffffu));
                 int r_nx = (int)Q.res[j];
@@ -549,6 +554,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_num_vgpr(100))) void
                     Q.T[base + pix] = (uint8_t)clip255(pred + r);
                     WAVE_SYNC();
                 }
+                __builtin_amdgcn_s_setprio(0);
             } else {
                 // Intra 8x8: h264_intra_prediction.c:1107-1353 (edge filter) + :1366-1793 + transform8x8_luma;
                 // lane j predicts samples (4*(j&1) .. +3, j>>1) of the block
