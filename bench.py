@@ -55,7 +55,7 @@ def parse_args():
     return ap.parse_args()
 
 
-PMC_SUMMARY = "r01_v5_pmc_summary.json"
+PMC_SUMMARY = "r01_v6_pmc_summary.json"
 
 
 def measured_traffic(args, fused, kernel):
