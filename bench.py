@@ -159,7 +159,7 @@ def main():
     hot.set_layout(args.layout)
     # which reconstruction kernel the library picks (mirrors pick_quad() in hotpath_abi.hip: speed only)
     n_cus = torch.cuda.get_device_properties(dev).multi_processor_count
-    octl = args.layout == "oct" or (args.layout == "auto" and F >= 8 * n_cus)
+    octl = args.layout == "oct" or (args.layout == "auto" and F >= 8 * n_cus and not (params.flags & 1))
     quad = not octl and (args.layout == "quad" or (args.layout == "auto" and F >= 3 * n_cus))
     recon_name = "recon_oct_kernel" if octl else ("recon_quad_kernel" if quad else "recon_rows_kernel")
     fused = want_rgb and not args.no_fused

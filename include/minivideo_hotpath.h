@@ -92,8 +92,12 @@ typedef struct mvhp_stream_params {
     uint32_t height_mbs;                     /* PicHeightInMapUnits (frame MBs only)   */
     int32_t  chroma_qp_index_offset;         /* PPS, Cb (h264_transform.c:611-618)     */
     int32_t  second_chroma_qp_index_offset;  /* PPS, Cr                                */
-    uint32_t flags;                          /* reserved                               */
+    uint32_t flags;                          /* MVHP_PARAM_* hints (speed only)        */
 } mvhp_stream_params_t;
+
+/* flags: the batch may contain Intra8x8 macroblocks (PPS transform_8x8_mode_flag).  A hint for the kernel choice
+ * only -- every kernel reconstructs every macroblock kind; callers that build records themselves may leave it 0. */
+#define MVHP_PARAM_MAY_HAVE_8X8 1u
 
 /* Bytes of one reconstructed picture: planar Y | Cb | Cr of the *uncropped*
  * coded size (export.c:80-81), and interleaved RGB8. */

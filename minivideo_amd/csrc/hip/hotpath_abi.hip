@@ -182,7 +182,8 @@ static int pick_layout(const mvhp_ctx *c, const mvhp_stream_params_t *p, int n_f
         layout = (n_frames >= 3 * c->n_cus) ? MVHP_LAYOUT_QUAD : MVHP_LAYOUT_ROWS;
         // eight pictures per workgroup (one 8-wave workgroup per CU) from 8 * CUs pictures: fewer instructions per
         // macroblock and full-line writes; measured 1.18x the four-picture kernel with RGB output, equal without
-        if (n_frames >= 8 * c->n_cus) layout = MVHP_LAYOUT_OCT;
+        // (Intra8x8-heavy batches run faster on the four-picture kernel: 1.21 vs 1.11 x 10^9 MB/s)
+        if (n_frames >= 8 * c->n_cus && !(p->flags & MVHP_PARAM_MAY_HAVE_8X8)) layout = MVHP_LAYOUT_OCT;
     }
     // the batch kernels address a workgroup's pictures with 32-bit offsets and keep one line buffer per picture in LDS
     const size_t mbs = (size_t)p->width_mbs * p->height_mbs;

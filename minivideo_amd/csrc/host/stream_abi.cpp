@@ -170,7 +170,7 @@ MVHP_EXPORT int mvhp_stream_params(const mvhp_stream_t *s, int idr, mvhp_stream_
     out->height_mbs = (uint32_t)i.sps.height_map_units;
     out->chroma_qp_index_offset = i.pps.chroma_qp_index_offset;
     out->second_chroma_qp_index_offset = i.pps.second_chroma_qp_index_offset;
-    out->flags = 0;
+    out->flags = i.pps.transform_8x8_mode ? MVHP_PARAM_MAY_HAVE_8X8 : 0u;
     return MVHP_SUCCESS;
 }
 
