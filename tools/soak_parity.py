@@ -22,7 +22,7 @@ while time.time() - t0 < budget:
     prof = ["baseline", "high"][int(rng.integers(0, 2))]
     dens = ["dense", "light"][int(rng.integers(0, 2))]
     lo = int(rng.integers(0, 40)); hi = int(rng.integers(lo, 52))
-    layout = ["rows", "quad"][int(rng.integers(0, 2))]
+    layout = ["rows", "quad", "oct"][int(rng.integers(0, 3))]
     waves = [0, 4, 6, 8, 12, 16][int(rng.integers(0, 6))]
     rgb = bool(rng.integers(0, 2))
     kw = dict(profile=prof, density=dens, qp_range=(lo, hi), cqp_offsets=(int(rng.integers(-12, 13)), int(rng.integers(-12, 13))))
