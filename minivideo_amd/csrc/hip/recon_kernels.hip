@@ -25,6 +25,7 @@
 #include "minivideo_hotpath.h"
 #include "recon_kernels.h"
 #include "recon_device.h"
+#include "recon_batch_device.h"
 
 namespace mvhp {
 
@@ -709,21 +710,13 @@ __global__ __launch_bounds__(NW * 64) void recon_rows_kernel(ReconArgs a)
                             const uint32_t yw = *reinterpret_cast<const uint32_t *>(&Wv.SY[y * 64 + x4]);
                             const uint32_t cbw = *reinterpret_cast<const uint16_t *>(&Wv.SC[0][(y >> 1) * 32 + (x4 >> 1)]);
                             const uint32_t crw = *reinterpret_cast<const uint16_t *>(&Wv.SC[1][(y >> 1) * 32 + (x4 >> 1)]);
-                            uint32_t o[12];
-#pragma unroll
-                            for (int q = 0; q < 4; q++) {
-                                const int l = (yw >> (q * 8)) & 255;
-                                const int cb = (cbw >> ((q >> 1) * 8)) & 255, cr = (crw >> ((q >> 1) * 8)) & 255;
-                                const int ly = (298 * l) >> 8;
-                                o[q * 3 + 0] = (uint32_t)clip255(ly + ((408 * cr) >> 8) - 222);
-                                o[q * 3 + 1] = (uint32_t)clip255(ly - ((100 * cb) >> 8) - ((208 * cr) >> 8) + 135);
-                                o[q * 3 + 2] = (uint32_t)clip255(ly + ((516 * cb) >> 8) - 276);
-                            }
+                            int d0, d1, d2;   // packed 16-bit arithmetic, see recon_batch_device.h rgb4()
+                            rgb4(yw, bytes01(cbw), bytes01(crw), d0, d1, d2);
                             uint32_t *dst = reinterpret_cast<uint32_t *>(
                                 frgb + ((size_t)(row * 16 + y) * pitch + x0 * 16 + x4) * 3);
-                            dst[0] = o[0] | (o[1] << 8) | (o[2] << 16) | (o[3] << 24);
-                            dst[1] = o[4] | (o[5] << 8) | (o[6] << 16) | (o[7] << 24);
-                            dst[2] = o[8] | (o[9] << 8) | (o[10] << 16) | (o[11] << 24);
+                            dst[0] = (uint32_t)d0;
+                            dst[1] = (uint32_t)d1;
+                            dst[2] = (uint32_t)d2;
                         }
                     }
                 }
