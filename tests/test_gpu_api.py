@@ -187,3 +187,44 @@ def test_stream_to_gpu_matches_oracle_high_4k(hot):
     ryuv, rrgb = loader.recon(p, got, 1, want_rgb=True)
     assert np.array_equal(yuv, ryuv) and np.array_equal(rgb, rrgb)
     assert yuv.size == 12441600
+
+
+def _idr_sample_sizes(stream_bytes):
+    """Sample table of the ES parser (esparser.c:40-143): indexed NALs are 00 00 00 01 + {0x65,0x67,0x68}; a sample runs
+    from its NAL header byte to the next indexed NAL header (or EOF); the scan stops 32 bytes before EOF."""
+    b = stream_bytes
+    pos = [i + 4 for i in range(len(b) - 32) if b[i:i + 4] == b"\x00\x00\x00\x01" and b[i + 4] in (0x65, 0x67, 0x68)]
+    sizes = []
+    for k, p in enumerate(pos):
+        end = pos[k + 1] if k + 1 < len(pos) else len(b)
+        if b[p] == 0x65:
+            sizes.append(end - p)
+    return sizes
+
+
+@pytest.mark.parametrize("mode", ["ordered", "distributed"])
+def test_cli_idr_selection_modes(tmp_path, mode):
+    """filter.c:94-211: keep IDR pictures larger than mean/1.66, then the first N (ordered) or every (T/(N-1))-th."""
+    W, H, F, N = 6, 4, 10, 3
+    # alternate dense and light pictures so that the size filter has something to drop
+    parts, packed = [], []
+    for k in range(F):
+        st, pk = gen.make_stream(W, H, 1, seed=50 + k, profile="baseline", dense=(k % 3 != 1))
+        b = st.tobytes()
+        if k:   # one SPS/PPS at the start of the file only
+            b = b[b.index(b"\x00\x00\x00\x01\x65"):]
+        parts.append(b.rstrip(b"\x00") if k < F - 1 else b)
+        packed.append(pk[0])
+    data = b"".join(parts)
+    sizes = _idr_sample_sizes(data)
+    assert len(sizes) == F
+    thr = int((sum(sizes) / F) / 1.66)
+    cand = [i for i in range(F) if sizes[i] > thr]
+    assert 0 < len(cand) < F
+    n = min(N, len(cand))
+    jump = len(cand) // (n - 1)
+    want = [cand[min(i if mode == "ordered" else i * jump, len(cand) - 1)] for i in range(n)]
+    _run(tmp_path, np.frombuffer(data, np.uint8), "sel.264", "-f", "yuv420", "-n", str(N), "-e", mode)
+    exp = _expected(W, H, packed)
+    for k, f in enumerate(want):
+        assert np.array_equal(np.fromfile(tmp_path / f"sel_{k}.yuv", np.uint8), exp[f][0]), (k, f)
