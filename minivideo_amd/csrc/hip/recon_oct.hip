@@ -513,33 +513,32 @@ __global__ __launch_bounds__(NW * 64) void recon_oct_kernel(ReconArgs a)
                 const uint8_t *T = Q.T;
                 const uint8_t *tapb = reinterpret_cast<const uint8_t *>(B.tap4) + j * 4;
                 const int32_t *res32 = reinterpret_cast<const int32_t *>(Q.res) + j;
-                // software pipeline: control word, table entries and residuals of block b+1 are fetched before block
-                // b's dependent tile reads
+                // The 16 blocks run in TEN dependent steps: block (bx, by) only needs blocks decoded at bx + 2*by - 1 or
+                // earlier (left, up, up-left and -- where the standard lets it be used at all -- up-right), so the two
+                // blocks of an anti-diagonal go together and their LDS round trips overlap.  Control word, table
+                // entries and residuals of the next step are fetched before this step's dependent tile reads.
                 __builtin_amdgcn_s_setprio(MVHP_CHAIN_PRIO);   // the dependent chain issues few, latency-critical instructions
-                uint32_t inf = (uint32_t)__builtin_amdgcn_ds_bpermute(obase4, (int)info[0]);
-                uint32_t ea_nx = *reinterpret_cast<const uint32_t *>(tapb + ((inf >> 8) & 0xffffu));
-                uint32_t eb_nx = *reinterpret_cast<const uint32_t *>(tapb + ((inf >> 8) & 0xffffu) + 32);
-                int r_nx = res32[0];
-#pragma unroll
-                for (int blk = 0; blk < 16; blk++) {
+                constexpr int SA[10] = {0, 1, 2, 3, 6, 7, 10, 11, 14, 15};
+                constexpr int SB[10] = {-1, -1, 4, 5, 8, 9, 12, 13, -1, -1};
+                struct Ctl { uint32_t inf, ea, eb; int r; };
+                auto fetch = [&](const int blk) {
+                    Ctl c;
+                    c.inf = (uint32_t)__builtin_amdgcn_ds_bpermute(obase4 + (blk >> 1) * 4, (int)info[blk & 1]);
+                    c.ea = *reinterpret_cast<const uint32_t *>(tapb + ((c.inf >> 8) & 0xffffu));
+                    c.eb = *reinterpret_cast<const uint32_t *>(tapb + ((c.inf >> 8) & 0xffffu) + 32);
+                    c.r = res32[blk * 8];
+                    return c;
+                };
+                auto predict = [&](const int blk, const Ctl &c) -> uint32_t {   // byte 0: upper sample, byte 1: lower
                     const int bxO = (((blk >> 2) & 1) << 3) | ((blk & 1) << 2);
                     const int byO = ((blk >> 3) << 3) | (((blk >> 1) & 1) << 2);
                     const int base = (byO + 1) * 32 + 16 + bxO;     // tile index of the block's top-left sample
-                    const uint32_t cur = inf;
-                    const uint32_t ea = ea_nx, eb = eb_nx;
-                    const int r = r_nx;
-                    if (blk < 15) {
-                        inf = (uint32_t)__builtin_amdgcn_ds_bpermute(obase4 + ((blk + 1) >> 1) * 4, (int)info[(blk + 1) & 1]);
-                        ea_nx = *reinterpret_cast<const uint32_t *>(tapb + ((inf >> 8) & 0xffffu));
-                        eb_nx = *reinterpret_cast<const uint32_t *>(tapb + ((inf >> 8) & 0xffffu) + 32);
-                        r_nx = res32[(blk + 1) * 8];
-                    }
-                    const int okmask = ((int)(cur << 28)) >> 31;   // bit 3 -> 0 / -1
-                    const int a0 = T[base - 33 + (int)(ea & 255)], b0 = T[base - 33 + (int)((ea >> 8) & 255)], c0 = T[base - 33 + (int)(ea >> 16)];
-                    const int a1 = T[base - 33 + (int)(eb & 255)], b1 = T[base - 33 + (int)((eb >> 8) & 255)], c1 = T[base - 33 + (int)(eb >> 16)];
+                    const int okmask = ((int)(c.inf << 28)) >> 31;   // bit 3 -> 0 / -1
+                    const int a0 = T[base - 33 + (int)(c.ea & 255)], b0 = T[base - 33 + (int)((c.ea >> 8) & 255)], c0 = T[base - 33 + (int)(c.ea >> 16)];
+                    const int a1 = T[base - 33 + (int)(c.eb & 255)], b1 = T[base - 33 + (int)((c.eb >> 8) & 255)], c1 = T[base - 33 + (int)(c.eb >> 16)];
                     int p0 = ((a0 + 2 * b0 + c0 + 2) >> 2) & okmask;
                     int p1 = ((a1 + 2 * b1 + c1 + 2) >> 2) & okmask;
-                    const bool isdc = (int)cur < 0;
+                    const bool isdc = (int)c.inf < 0;
                     if (__builtin_amdgcn_ballot_w64(isdc) != 0) { // some picture predicts DC
                         // which neighbours exist is positional, i.e. the same for the eight pictures: scalar branches
                         const bool bl = (bxO > 0) || A, bu = (byO > 0) || Bv;
@@ -556,9 +555,28 @@ __global__ __launch_bounds__(NW * 64) void recon_oct_kernel(ReconArgs a)
                         p0 = isdc ? dcv : p0;
                         p1 = isdc ? dcv : p1;
                     }
-                    const uint32_t two = sat_pk_u8(pk_add_sat(p0 | (p1 << 16), r));   // byte 0: upper sample, byte 1: lower
+                    return sat_pk_u8(pk_add_sat(p0 | (p1 << 16), c.r));
+                };
+                auto put = [&](const int blk, const uint32_t two) {
+                    const int bxO = (((blk >> 2) & 1) << 3) | ((blk & 1) << 2);
+                    const int byO = ((blk >> 3) << 3) | (((blk >> 1) & 1) << 2);
+                    const int base = (byO + 1) * 32 + 16 + bxO;
                     Q.T[base + pix] = (uint8_t)two;
                     Q.T[base + pix + 64] = (uint8_t)(two >> 8);
+                };
+                Ctl nA = fetch(0), nB = nA;
+#pragma unroll
+                for (int t = 0; t < 10; t++) {
+                    const Ctl cA = nA, cB = nB;
+                    if (t < 9) {
+                        nA = fetch(SA[t + 1]);
+                        if (SB[t + 1] >= 0) nB = fetch(SB[t + 1]);
+                    }
+                    const uint32_t twoA = predict(SA[t], cA);
+                    uint32_t twoB = 0;
+                    if (SB[t] >= 0) twoB = predict(SB[t], cB);
+                    put(SA[t], twoA);
+                    if (SB[t] >= 0) put(SB[t], twoB);
                     WAVE_SYNC();
                 }
                 __builtin_amdgcn_s_setprio(0);
