@@ -22,8 +22,13 @@ struct __attribute__((aligned(16))) QLds {
     uint8_t LcolC[2][8];     // compact left neighbour columns (Cb, Cr)
     uint8_t E8[32];          // filtered Intra8x8 edge, see recon_device.h mode_entry()
     uint8_t SC[2][8 * 24];   // output strip, chroma: rows of the three parked macroblocks (the fourth flushes from registers)
-};                           // 1808 B: quarters land 452 dwords apart (different banks)
+#ifdef MVHP_QLDS_PAD
+    uint8_t pad[MVHP_QLDS_PAD];  // measurement builds: bank offset between the pictures of a wavefront
+#endif
+};                           // 1808 B: pictures land 452 dwords apart (different banks)
+#ifndef MVHP_QLDS_PAD
 static_assert(sizeof(QLds) == 1808, "QLds layout");
+#endif
 
 struct __attribute__((aligned(16))) QTables {
     int      progress[16];   // macroblocks completed by wave w (monotonic over its rows)
