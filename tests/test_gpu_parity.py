@@ -89,6 +89,12 @@ def test_full_hd_frames(hot):
     _check(hot, params, rec, 2)
 
 
+def test_full_hd_several_workgroups(hot):
+    # 17 pictures: five workgroups of four / three of eight, the last one short
+    params, rec = synth_packed(120, 68, 17, seed=1081, profile="baseline", density="dense")
+    _check(hot, params, rec, 17)
+
+
 def test_4k_frame_high(hot):
     params, rec = synth_packed(240, 135, 1, seed=2160, profile="high", density="dense")
     _check(hot, params, rec, 1)
