@@ -32,3 +32,31 @@ def _check_one(tmp_path, name):
     assert "flat_load" not in text and "flat_store" not in text      # LDS counters must be ds_ operations
     # (register spills inside the macroblock loop would be vector-memory operations the counted waits do not know
     # about: check_prefetch_hazard rejects them; a spill of a loop-invariant outside that loop is harmless)
+
+
+def test_checker_catches_violations(tmp_path):
+    """The safety net itself: inject (a) a compiler-style instruction that touches a prefetch register while the loads
+    are in flight, (b) an extra asm store into the loop, (c) a scratch access into the loop -- each must be rejected."""
+    import re
+    out = tmp_path / "recon_quad.s"
+    src = os.path.join(ROOT, "minivideo_amd", "csrc", "hip", "recon_quad.hip")
+    r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-I" + os.path.join(ROOT, "include"),
+                        "-I" + os.path.dirname(src), src, "--cuda-device-only", "-S", "-o", str(out)],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import check_prefetch_hazard as chk
+    lines = out.read_text().split("\n")
+    # the last asm load block of the first kernel = the prefetch inside the macroblock loop
+    k0 = next(i for i, l in enumerate(lines) if re.match(r"^_ZN4mvhp17recon_quad_kernel\S+:", l))
+    k1 = next(i for i in range(k0, len(lines)) if "s_endpgm" in lines[i])
+    loads = [i for i in range(k0, k1) if "global_load_dwordx4 v[120:123]" in lines[i]]
+    at = loads[-1] + 2          # behind the #ASMEND of the block
+    for inject in ("\tv_mov_b32_e32 v101, v1",
+                   "\t;;#ASMSTART\n\tglobal_store_dwordx4 v1, v[2:5], s[0:1]\n\t;;#ASMEND",
+                   "\tscratch_load_dword v1, off, off"):
+        bad = lines[:at] + inject.split("\n") + lines[at:]
+        p = tmp_path / "bad.s"
+        p.write_text("\n".join(bad))
+        with pytest.raises(AssertionError):
+            chk.main(str(p))
