@@ -25,6 +25,9 @@
 
 namespace mvhp {
 
+#ifndef MVHP_LOAD_HINT
+#define MVHP_LOAD_HINT ""   // cache-policy suffix of the record loads (measurement builds try " nt")
+#endif
 #ifndef MVHP_CHAIN_PRIO
 #define MVHP_CHAIN_PRIO 2   // wave priority inside the Intra4x4 chain (measured: 0 -> 2 = -2 % / -6 % kernel time with / without RGB)
 #endif
@@ -104,14 +107,14 @@ __global__ __launch_bounds__(NW * 64) void recon_oct_kernel(ReconArgs a)
         const uint32_t recL = rec + MVHP_MB_HEADER_BYTES + jj * 64;
         const uint32_t recC = rec + MVHP_MB_HEADER_BYTES + (16 + jj) * 32;
         asm volatile("s_nop 4\n\t"
-                     "global_load_dwordx4 v[216:219], %0, %3\n\t"
-                     "global_load_dwordx4 v[220:223], %0, %3 offset:16\n\t"
-                     "global_load_dwordx4 v[224:227], %1, %3\n\t"
-                     "global_load_dwordx4 v[228:231], %1, %3 offset:16\n\t"
-                     "global_load_dwordx4 v[232:235], %1, %3 offset:32\n\t"
-                     "global_load_dwordx4 v[236:239], %1, %3 offset:48\n\t"
-                     "global_load_dwordx4 v[240:243], %2, %3\n\t"
-                     "global_load_dwordx4 v[244:247], %2, %3 offset:16"
+                     "global_load_dwordx4 v[216:219], %0, %3" MVHP_LOAD_HINT "\n\t"
+                     "global_load_dwordx4 v[220:223], %0, %3 offset:16" MVHP_LOAD_HINT "\n\t"
+                     "global_load_dwordx4 v[224:227], %1, %3" MVHP_LOAD_HINT "\n\t"
+                     "global_load_dwordx4 v[228:231], %1, %3 offset:16" MVHP_LOAD_HINT "\n\t"
+                     "global_load_dwordx4 v[232:235], %1, %3 offset:32" MVHP_LOAD_HINT "\n\t"
+                     "global_load_dwordx4 v[236:239], %1, %3 offset:48" MVHP_LOAD_HINT "\n\t"
+                     "global_load_dwordx4 v[240:243], %2, %3" MVHP_LOAD_HINT "\n\t"
+                     "global_load_dwordx4 v[244:247], %2, %3 offset:16" MVHP_LOAD_HINT ""
                      : : "v"(rec), "v"(recL), "v"(recC), "s"(gpacked)
                      : "memory", "v216", "v217", "v218", "v219", "v220", "v221", "v222", "v223", "v224", "v225", "v226", "v227",
                        "v228", "v229", "v230", "v231", "v232", "v233", "v234", "v235", "v236", "v237", "v238", "v239",
