@@ -15,6 +15,7 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 h = HotPath(0)
 t0 = time.time()
 n_cases = n_mb = 0
+t_print = t0
 while time.time() - t0 < budget:
     W = int(rng.integers(1, 40)); H = int(rng.integers(1, 40)); n = int(rng.integers(1, 14))
     if rng.random() < 0.1:
@@ -38,4 +39,7 @@ while time.time() - t0 < budget:
         print("MISMATCH", W, H, n, prof, dens, (lo, hi), layout, waves, rgb, kw, flush=True)
         sys.exit(1)
     n_cases += 1; n_mb += W * H * n
+    if time.time() - t_print > 30:   # progress line (a silent GPU job is taken to be hung)
+        t_print = time.time()
+        print("... %d cases, %d macroblocks, %.0f s" % (n_cases, n_mb, time.time() - t0), flush=True)
 print("soak ok: %d cases, %d macroblocks, %.0f s" % (n_cases, n_mb, time.time() - t0))
