@@ -162,6 +162,13 @@ __global__ __launch_bounds__(NW * 64) void recon_oct_kernel(ReconArgs a)
             if (n_st) MVHP_WAIT_PREFETCH(VM_STRIP);
             else MVHP_WAIT_PREFETCH(0);
 #undef MVHP_WAIT_PREFETCH
+            {   // the record has been moved out of the prefetch registers: request the next macroblock of this wave at
+                // once -- same row, or the first of its next row (none left: this one again)
+                int nrow = row, nx = mbx + 1;
+                if (nx >= W) { nrow = row + NW; nx = 0; }
+                if (nrow >= H) { nrow = row; nx = mbx; }
+                prefetch(nrow, nx, lane);
+            }
             const uint32_t h0 = (uint32_t)w[0].x, h1 = (uint32_t)w[0].y, nz = (uint32_t)w[1].x;
             const uint32_t m0 = (uint32_t)w[1].y, m1 = (uint32_t)w[2].x, m2 = (uint32_t)w[2].y, m3 = (uint32_t)w[3].x;
             const int kind = h0 & 255;
@@ -348,14 +355,6 @@ __global__ __launch_bounds__(NW * 64) void recon_oct_kernel(ReconArgs a)
 #pragma unroll
                     for (int i = 0; i < 8; i++) c2[i] = 0;
                 }
-            }
-
-            {   // the record is consumed: prefetch the next macroblock of this wave -- same row, or the first of its
-                // next row (none left: this one again)
-                int nrow = row, nx = mbx + 1;
-                if (nx >= W) { nrow = row + NW; nx = 0; }
-                if (nrow >= H) { nrow = row; nx = mbx; }
-                prefetch(nrow, nx, lane);
             }
 
             // =====================================================================================
