@@ -209,16 +209,16 @@ static int pick_waves(const mvhp_ctx *c, const mvhp_stream_params_t *p, int n_fr
         return 4;
     }
     if (layout == MVHP_LAYOUT_QUAD) {
-        // speed only: the quad kernel is built for 4, 6, 8 and 12 waves (at 16 its register budget would force
-        // spills); 8-wave workgroups fit two to a CU (LDS, 128 VGPRs) = 16 waves per CU
-        static const int opts[4] = {12, 8, 6, 4};
+        // speed only: built for 4, 6, 8, 12 and 16 waves; 8-wave workgroups fit two to a CU (LDS, 128 VGPRs) = 16 waves
+        // per CU; when only one workgroup per CU will be resident (few workgroups, or wide pictures whose four line
+        // buffers leave LDS for one), it should bring the 16 waves itself
+        static const int opts[5] = {16, 12, 8, 6, 4};
         if (nw == 0) {
-            // two 8-wave workgroups per CU when there are enough workgroups and LDS for that, else one of 12
             const int groups = (n_frames + 3) / 4;
             const bool two_fit = 2 * mvhp::recon_quad_lds_bytes((int)p->width_mbs, 8) <= c->max_lds;
-            nw = (groups >= 2 * c->n_cus && two_fit) ? 8 : 12;
+            nw = (groups >= 2 * c->n_cus && two_fit) ? 8 : 16;
         }
-        for (int k = 0; k < 4; k++) {
+        for (int k = 0; k < 5; k++) {
             const int o = opts[k];
             if (o > nw) continue;
             if (o > 4 && ((o + 1) / 2 >= (int)p->height_mbs || mvhp::recon_quad_lds_bytes((int)p->width_mbs, o) > c->max_lds)) continue;

@@ -807,6 +807,7 @@ hipError_t launch_recon_quad(const ReconArgs &a, int nw, hipStream_t stream)
     case 6: return rgb ? launch_quad_one<6, true>(a, stream) : launch_quad_one<6, false>(a, stream);
     case 8: return rgb ? launch_quad_one<8, true>(a, stream) : launch_quad_one<8, false>(a, stream);
     case 12: return rgb ? launch_quad_one<12, true>(a, stream) : launch_quad_one<12, false>(a, stream);
+    case 16: return rgb ? launch_quad_one<16, true>(a, stream) : launch_quad_one<16, false>(a, stream);
     default: return hipErrorInvalidValue;
     }
 }
