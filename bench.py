@@ -1,21 +1,28 @@
 #!/usr/bin/env python3
-"""bench.py -- macroblocks/s of the MI355X-native H.264 intra reconstruction hot path.
+"""bench.py -- macroblocks/s of the MI355X-native H.264 intra (IDR) decode path.
 
-Contract: `python bench.py --gpus N --steps K --warmup W` (N>1 under
-torch.distributed.run, one rank per GPU).  One "step" = one pass of the hot path
-(reconstruction kernel + colour kernel) over one batch of synthetic 1080p
-Baseline pictures whose packed macroblock records are already resident in HBM.
-Frames are independent, so ranks share nothing on the data path (weak scaling:
-every rank processes its own batch); torch.distributed is used only for the
+Contract: `python bench.py --gpus N --steps K --warmup W`.  N > 1 runs one rank per GPU: either the caller starts the
+ranks (`python -m torch.distributed.run ... bench.py --gpus N`), or, started bare, bench.py starts them itself before
+anything touches a GPU; `--gpus` and WORLD_SIZE must agree, a mismatch is an error (never a silent 1-GPU run).
+
+`value`: one "step" = one pass of the reconstruction hot path (dequantisation, IDCT, intra prediction, reconstruction,
+fused RGB) over one batch of synthetic pictures whose packed macroblock records are already resident in HBM
+(default: BASELINE.json configs[1], 2048 x 1080p Baseline per GPU, weak scaling; `--strong P` = configs[4], P pictures
+split over the ranks).  Frames are independent: ranks share nothing on the data path; torch.distributed is only the
 barrier and the max-over-ranks clock.
 
-Rank 0 prints ONE JSON line with `roofline` (dominant kernel, HIP events on the
-launch stream) and, at N=1, `cpu_baseline` (the CPU restatement in oracle/,
-one thread, bounded sample).
+Rank 0 prints ONE JSON line with, besides the contract's keys,
+  roofline      dominant kernel: algorithmic bytes / HIP-event duration against the 8 TB/s HBM peak;
+  end_to_end    SURVEY 8(d)'s definition of the metric: stream bytes in host memory -> entropy decode on the host
+                cores -> H2D -> kernels -> D2H -> planes + RGB in page-locked host memory (mvhp_engine_decode, the
+                pipeline behind minivideo_decode), with the share of each stage and which one binds;
+  cpu_baseline  (N = 1) the CPU restatement (oracle/, kind "port") on a bounded sample: reconstruction only (the span
+                of `value`) and front end + reconstruction (the span of end_to_end), one thread and all host cores.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -35,9 +42,10 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--frames", type=int, default=2048, help="pictures per GPU per step (512 four-picture workgroups = "
-                    "two 8-wave workgroups on each of the 256 CUs)")
-    ap.add_argument("--distinct", type=int, default=16, help="distinct synthetic pictures tiled to --frames")
+    ap.add_argument("--frames", type=int, default=2048, help="pictures per GPU per step (weak scaling)")
+    ap.add_argument("--strong", type=int, default=0, metavar="P",
+                    help="strong scaling: P pictures per step in total, split over the ranks (BASELINE.json configs[4]: 512)")
+    ap.add_argument("--distinct", type=int, default=16, help="distinct synthetic pictures tiled to the batch")
     ap.add_argument("--width-mbs", type=int, default=120)
     ap.add_argument("--height-mbs", type=int, default=68)
     ap.add_argument("--profile", default="baseline", choices=["baseline", "high"])
@@ -47,61 +55,229 @@ def parse_args():
                          "records: random packed records drawn directly (minivideo_amd.synth)")
     ap.add_argument("--waves", type=int, default=0)
     ap.add_argument("--layout", default="auto", choices=["auto", "rows", "quad", "oct"],
-                    help="pictures per workgroup: rows = 1 (one wavefront per macroblock row), quad = 4 (16 lanes per picture)")
+                    help="pictures per workgroup: rows = 1 (one wavefront per macroblock row), quad = 4, oct = 8")
     ap.add_argument("--no-rgb", action="store_true")
     ap.add_argument("--no-fused", action="store_true", help="run the colour conversion as its own kernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--cpu-seconds", type=float, default=5.0, help="budget of each of the four CPU baseline legs")
+    ap.add_argument("--e2e-pictures", type=int, default=-1,
+                    help="pictures of the end-to-end leg, in total over the ranks (-1: 512, or P with --strong; 0: skip)")
+    ap.add_argument("--e2e-batch", type=int, default=0, help="pictures per launch in the end-to-end leg (0: engine default)")
+    ap.add_argument("--host-threads", type=int, default=0, help="entropy threads per rank (0: host cores / ranks)")
     return ap.parse_args()
 
 
-PMC_SUMMARY = "r01_v6_pmc_summary.json"
+def spawn_ranks(args):
+    """--gpus N > 1 without a launcher: start the N ranks ourselves, before anything touches a GPU."""
+    import socket
+    import torch
+    have = torch.cuda.device_count()   # (counting devices does not initialise the GPU on this image)
+    if have < args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but only {have} HIP device(s) are visible")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd, env=env))
 
 
-def measured_traffic(args, fused, kernel):
+def measured_traffic(args, fused, kernel, frames):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes of THIS command
-    (tools/pmc_profile.sh: FETCH_SIZE and WRITE_SIZE in separate passes; FETCH_SIZE doubled per the gfx950
-    correction in MI355X_MICROARCH.md).  Only reported when the run uses the profiled configuration."""
-    path = os.path.join(ROOT, "profiles", PMC_SUMMARY)
-    default = (args.frames == 2048 and args.width_mbs == 120 and args.height_mbs == 68 and args.profile == "baseline"
-               and args.density == "dense" and args.source == "stream" and fused and not args.waves and args.layout == "auto")
-    if not (default and os.path.exists(path)):
+    (tools/profile_config.sh: FETCH_SIZE and WRITE_SIZE in separate passes; FETCH_SIZE doubled per the gfx950
+    correction in MI355X_MICROARCH.md).  Only reported when the run uses a profiled configuration."""
+    if not (args.density == "dense" and args.source == "stream" and fused and not args.waves and args.layout == "auto"
+            and not args.strong):
         return None, None
-    d = json.load(open(path)).get(kernel.split(" ")[0], {})
-    if "hbm_read_bytes_corrected" not in d or "hbm_write_bytes" not in d:
+    tag = {("baseline", 120, 68, 2048): "base1080", ("high", 120, 68, 2048): "high1080",
+           ("high", 240, 135, 1024): "high2160"}.get((args.profile, args.width_mbs, args.height_mbs, frames))
+    if tag is None:
         return None, None
-    return d["hbm_read_bytes_corrected"] + d["hbm_write_bytes"], "profiles/" + PMC_SUMMARY
+    for rnd in ("r02b", "r02a"):
+        name = f"{rnd}_{tag}_pmc_summary.json"
+        path = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(path):
+            d = json.load(open(path)).get(kernel.split(" ")[0], {})
+            if "hbm_read_bytes_corrected" in d and "hbm_write_bytes" in d:
+                return d["hbm_read_bytes_corrected"] + d["hbm_write_bytes"], "profiles/" + name
+    return None, None
 
 
-def cpu_baseline(params, rec, want_rgb, budget_s):
-    """Time the CPU restatement (oracle/, kind "port") on a bounded sample of the same workload."""
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def repeat_stream(stream, n_distinct, total):
+    """An Annex-B stream of `total` pictures: the parameter sets once, then the `n_distinct` IDR NAL units of `stream`
+    over and over (every picture is entropy-decoded again; the 64 trailing zero bytes the ES index needs stay last)."""
+    s = stream
+    idx = np.flatnonzero((s[:-4] == 0) & (s[1:-3] == 0) & (s[2:-2] == 0) & (s[3:-1] == 1) & (s[4:] == 0x65))
+    assert len(idx) == n_distinct, "unexpected start codes inside the synthetic stream"
+    head, body, tail = s[:idx[0]], s[idx[0]:len(s) - 64], s[len(s) - 64:]
+    reps, rem = divmod(total, n_distinct)
+    parts = [head] + [body] * reps
+    if rem:
+        parts.append(s[idx[0]:idx[rem]])
+    return np.concatenate(parts + [tail])
+
+
+def cpu_baseline(params, stream, n_distinct, rec, want_rgb, budget_s):
+    """The CPU restatement on the host cores (kind "port"): oracle/recon_ref.c for the reconstruction stages, the
+    library's own host front end for the entropy stage it shares with the GPU path."""
+    import ctypes as C
+    from concurrent.futures import ThreadPoolExecutor
+    from minivideo_amd import lib
     from oracle import loader
-    n_have = rec.shape[0]
-    loader.recon(params, rec[:1], 1, want_rgb=want_rgb)  # warm
-    n = 0
-    t0 = time.perf_counter()
-    while True:
-        loader.recon(params, rec, n_have, want_rgb=want_rgb)
-        n += n_have
+    L = lib()
+    cores = os.cpu_count() or 1
+    h = C.c_void_p()
+    have_stream = stream is not None and L.mvhp_stream_open(stream.ctypes.data, stream.size, C.byref(h)) == 1
+    mbs = params.mbs
+
+    def recon_one(k):
+        loader.recon(params, rec[k % n_distinct], 1, want_rgb=want_rgb)
+
+    def e2e_one(k):
+        buf = np.empty(params.packed_bytes, np.uint8)
+        if L.mvhp_stream_decode_packed(h, k % n_distinct, buf.ctypes.data, buf.size) != 1:
+            raise RuntimeError("cpu_baseline: front end failed")
+        loader.recon(params, buf, 1, want_rgb=want_rgb)
+
+    def timed(fn, threads):
+        fn(0)   # warm
+        n, t0 = 0, time.perf_counter()
+        if threads == 1:
+            while time.perf_counter() - t0 < budget_s:
+                fn(n)
+                n += 1
+        else:   # ctypes releases the GIL inside the C calls: the threads run on all cores
+            with ThreadPoolExecutor(threads) as ex:
+                while time.perf_counter() - t0 < budget_s:
+                    list(ex.map(fn, range(n, n + 2 * threads)))
+                    n += 2 * threads
         dt = time.perf_counter() - t0
-        if dt >= budget_s:
-            break
-    return {
-        "value": n * params.mbs / dt,
+        return n * mbs / dt, n, dt
+
+    r1, n1, d1 = timed(recon_one, 1)
+    rN, nN, dN = timed(recon_one, cores)
+    out = {
+        "value": r1,
         "unit": "macroblocks/s",
         "cores": 1,
         "kind": "port",
-        "sample": f"{n} of the benchmark's 1080p pictures ({n * params.mbs} macroblocks, {dt:.1f} s), "
-                  f"oracle/recon_ref.c single thread, same stages as the GPU step",
+        "sample": f"{n1} of the benchmark's pictures ({n1 * mbs} macroblocks, {d1:.1f} s), oracle/recon_ref.c, one thread, "
+                  f"the stages of the GPU step (packed records -> planes" + (" -> RGB)" if want_rgb else ")"),
+        "cpu_model": cpu_model(),
+        "host_cores": cores,
+        "all_cores": {"value": rN, "cores": cores, "sample": f"{nN} pictures, {dN:.1f} s, one picture per thread"},
+    }
+    if have_stream:
+        e1, m1, t1 = timed(e2e_one, 1)
+        eN, mN, tN = timed(e2e_one, cores)
+        out["end_to_end"] = {
+            "span": "stream bytes -> host front end (entropy decode) -> oracle/recon_ref.c -> planes" + (" + RGB" if want_rgb else ""),
+            "value": e1, "unit": "macroblocks/s", "cores": 1, "sample": f"{m1} pictures, {t1:.1f} s",
+            "all_cores": {"value": eN, "cores": cores, "sample": f"{mN} pictures, {tN:.1f} s"},
+        }
+        L.mvhp_stream_close(h)
+    return out
+
+
+def end_to_end(args, params, stream, n_distinct, rec, want_rgb, total, rank, world, local_rank, dist, dev):
+    """stream bytes in host memory -> planes (+ RGB) in page-locked host memory, through the pipeline
+    behind minivideo_decode.  Every rank decodes its share of the pictures with its own engine on its own GPU."""
+    import ctypes as C
+    import torch
+    from minivideo_amd import Engine, lib
+    from minivideo_amd.dist import shard
+    L = lib()
+    cores = os.cpu_count() or 1
+    threads = args.host_threads or max(1, cores // world)
+    big = repeat_stream(stream, n_distinct, total)
+    h = C.c_void_p()
+    if L.mvhp_stream_open(big.ctypes.data, big.size, C.byref(h)) != 1 or L.mvhp_stream_idr_count(h) != total:
+        raise SystemExit("bench: the end-to-end stream failed to parse")
+    lo, hi = shard(total, rank, world)
+    order = list(range(lo, hi))
+    eng = Engine(contexts=1, host_threads=threads, batch_pictures=args.e2e_batch, first_device=local_rank)
+    check = sorted({0, 1, len(order) // 2, len(order) - 1} & set(range(len(order))))
+    kept = {}
+
+    def sink(seq, idr, rc, err, p, yuv, rgb):
+        if rc == 1 and seq in check:
+            kept[seq] = (idr, yuv.copy(), rgb.copy() if rgb is not None else None)
+        return 1 if rc == 1 else 0
+
+    # cold call: creates the page-locked pools and device buffers; then the timed call on the same engine
+    rc0, st0 = eng.decode(h, order[:max(1, min(len(order), 64))], want_rgb=want_rgb)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    rc, st = eng.decode(h, order, want_rgb=want_rgb, sink=sink)
+    torch.cuda.synchronize(dev)
+    wall = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([wall], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall = float(t.item())
+    eng.close()
+    L.mvhp_stream_close(h)
+    ok = rc == 1 and st["pictures_ok"] == len(order)
+    if rank == 0:
+        from oracle import loader
+        for seq, (idr, yuv, rgb) in kept.items():
+            ref, ref_rgb = loader.recon(params, rec[idr % n_distinct], 1, want_rgb=want_rgb)
+            ok = ok and bool(np.array_equal(yuv, ref)) and (not want_rgb or bool(np.array_equal(rgb, ref_rgb)))
+        ok = ok and len(kept) == len(check)
+    w = st["wall_s"]
+    stages = {
+        "entropy_decode_host": {"busy_s": st["entropy_busy_s"], "threads": st["host_threads"],
+                                "share_of_wall": st["entropy_busy_s"] / max(1, st["host_threads"]) / w},
+        "h2d": {"busy_s": st["h2d_s"], "share_of_wall": st["h2d_s"] / w, "GB/s": st["h2d_bytes"] / max(st["h2d_s"], 1e-9) / 1e9},
+        "kernels": {"busy_s": st["kernel_s"], "share_of_wall": st["kernel_s"] / w, "launches": st["batches"],
+                    "largest_batch": st["max_batch_pictures"],
+                    "by_layout": dict(zip(["auto", "rows", "quad", "oct"], st["launches_by_layout"]))},
+        "d2h": {"busy_s": st["d2h_s"], "share_of_wall": st["d2h_s"] / w, "GB/s": st["d2h_bytes"] / max(st["d2h_s"], 1e-9) / 1e9},
+    }
+    bound = max(stages, key=lambda k: stages[k]["share_of_wall"])
+    return {
+        "value": total * params.mbs / wall,
+        "unit": "macroblocks/s",
+        "span": "Annex-B bytes in host memory -> planes" + (" + RGB" if want_rgb else "") + " in page-locked host memory "
+                "(mvhp_engine_decode: entropy threads || H2D || kernels || D2H)",
+        "pictures": total,
+        "n_gpus": world,
+        "wall_s": wall,
+        "cold_call_s": st0["wall_s"],
+        "cold_call_pictures": st0["pictures_ok"],
+        "stream_bytes_per_picture": st["stream_bytes"] / max(1, len(order)),
+        "stages_rank0": stages,
+        "bound": bound,
+        "bit_exact_vs_oracle": ok,
     }
 
 
 def main():
     args = parse_args()
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        spawn_ranks(args)
+    world = int(env_world or "1")
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} does not match WORLD_SIZE={world}; launch one rank per GPU "
+                         f"(python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...)")
     import torch
     import torch.distributed as dist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
@@ -114,11 +290,21 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     from minivideo_amd import HotPath
+    from minivideo_amd.dist import shard
 
     want_rgb = not args.no_rgb
-    F = args.frames
+    if args.strong:
+        lo, hi = shard(args.strong, rank, world)
+        F = hi - lo
+        if F <= 0:
+            raise SystemExit("bench: --strong needs at least one picture per rank")
+        total_frames = args.strong
+    else:
+        F = args.frames
+        total_frames = F * world
     n_distinct = min(args.distinct, F)
     host_rate = None
+    stream = None
     if args.source == "stream":
         # the real input path: Annex-B bytes -> host entropy decode (CAVLC / CABAC) -> packed records
         import ctypes as C
@@ -157,30 +343,25 @@ def main():
     if args.waves:
         hot.set_waves_per_picture(args.waves)
     hot.set_layout(args.layout)
-    # which reconstruction kernel the library picks (mirrors pick_quad() in hotpath_abi.hip: speed only)
-    n_cus = torch.cuda.get_device_properties(dev).multi_processor_count
-    octl = args.layout == "oct" or (args.layout == "auto" and F >= 8 * n_cus and not (params.flags & 1))
-    quad = not octl and (args.layout == "quad" or (args.layout == "auto" and F >= 3 * n_cus))
-    recon_name = "recon_oct_kernel" if octl else ("recon_quad_kernel" if quad else "recon_rows_kernel")
     fused = want_rgb and not args.no_fused
     hot.set_fused_color(fused)
     # a dedicated (non-null) stream: the C-ABI treats a NULL stream as "the context's own stream",
     # and the HIP events below must sit on the stream the kernels are launched on.
-    stream = torch.cuda.Stream(device=dev)
-    sp = stream.cuda_stream
+    stream_t = torch.cuda.Stream(device=dev)
+    sp = stream_t.cuda_stream
     assert sp != 0
     rgb_ptr = d_rgb.data_ptr() if want_rgb else None
 
     def step(ev=None):
         if ev is not None:
-            ev[0].record(stream)
+            ev[0].record(stream_t)
         hot.recon_stages_dev(params, d_packed.data_ptr(), F, d_yuv.data_ptr(), rgb_ptr, sp, 3 if fused else 1)
         if ev is not None:
-            ev[1].record(stream)
+            ev[1].record(stream_t)
         if want_rgb and not fused:
             hot.recon_stages_dev(params, d_packed.data_ptr(), F, d_yuv.data_ptr(), rgb_ptr, sp, 2)
         if ev is not None:
-            ev[2].record(stream)
+            ev[2].record(stream_t)
 
     def barrier():
         if world > 1:
@@ -199,6 +380,8 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     hot.sync_check(sp)
+    layout_name, waves_used = hot.last_launch()   # what the library chose (speed only)
+    recon_name = {"rows": "recon_rows_kernel", "quad": "recon_quad_kernel", "oct": "recon_oct_kernel"}[layout_name]
 
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -209,9 +392,9 @@ def main():
     ms_color = float(np.mean([e[1].elapsed_time(e[2]) for e in events])) if (want_rgb and not fused) else 0.0
 
     mbs_per_step = F * params.mbs
-    value = world * mbs_per_step * args.steps / elapsed
+    value = total_frames * params.mbs * args.steps / elapsed
 
-    # spot-check one picture of the last step against the oracle (bit-exact) -- the checker, not the product
+    # spot-check pictures of the last step against the oracle (bit-exact) -- the checker, not the product
     ok = None
     if rank == 0:
         from oracle import loader
@@ -222,6 +405,15 @@ def main():
             ok = ok and bool(np.array_equal(d_yuv[f * params.yuv_bytes:(f + 1) * params.yuv_bytes].cpu().numpy(), ref))
             if want_rgb:
                 ok = ok and bool(np.array_equal(d_rgb[f * params.rgb_bytes:(f + 1) * params.rgb_bytes].cpu().numpy(), ref_rgb))
+    del d_packed, d_yuv, d_rgb
+    hot.close()
+    torch.cuda.empty_cache()
+
+    # ---- end to end (stream bytes -> host planes), every rank on its share ----
+    e2e_total = args.e2e_pictures if args.e2e_pictures >= 0 else (args.strong or 512)
+    e2e = None
+    if e2e_total >= world and stream is not None:
+        e2e = end_to_end(args, params, stream, n_distinct, rec, want_rgb, e2e_total, rank, world, local_rank, dist, dev)
 
     if rank == 0:
         dom_recon = ms_recon >= ms_color
@@ -232,7 +424,18 @@ def main():
         else:
             achieved = mbs_per_step * BYTES_PER_MB_COLOR / (ms_color * 1e-3) / 1e9
             kname = "ycbcr_to_rgb_kernel"
-        traffic, traffic_src = measured_traffic(args, fused, kname)
+        traffic, traffic_src = measured_traffic(args, fused, kname, F)
+        is_cfg = args.width_mbs == 120 and args.height_mbs == 68 and args.density == "dense"
+        if args.strong and is_cfg and args.profile == "baseline":
+            cfg = f"BASELINE.json configs[4]: {args.strong} independent 1080p IDR pictures per step sharded over {world} GPU(s)"
+        elif is_cfg and args.profile == "baseline":
+            cfg = "BASELINE.json configs[1]"
+        elif is_cfg and args.profile == "high":
+            cfg = "BASELINE.json configs[2]"
+        elif args.width_mbs == 240 and args.height_mbs == 135 and args.profile == "high":
+            cfg = "BASELINE.json configs[3]"
+        else:
+            cfg = "not a BASELINE.json configuration"
         out = {
             "metric": "macroblocks/s on 1080p H.264 IDR frames; 1/2/4/8-GPU scaling",
             "value": value,
@@ -242,7 +445,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if args.strong else "weak",
             "vs_baseline": None,
             "dtype": "int32",
             "data": (f"synthetic ({n_distinct} distinct {args.density} pictures of a generated "
@@ -252,19 +455,20 @@ def main():
             "config": {
                 "workload": f"{args.width_mbs * 16}x{args.height_mbs * 16} ({args.width_mbs}x{args.height_mbs} MB) "
                             f"{args.profile}-profile IDR pictures, {'4x4 transform only' if args.profile == 'baseline' else '4x4+8x8 transform'}, "
-                            f"{args.density} content (BASELINE.json configs[1])",
+                            f"{args.density} content ({cfg})",
                 "frames_per_gpu_per_step": F,
-                "macroblocks_per_step": world * mbs_per_step,
+                "macroblocks_per_step": total_frames * params.mbs,
                 "stages": "dequant+IDCT+intra prediction+reconstruct -> planar YCbCr" + (" -> RGB" if want_rgb else ""),
-                "parallelism": (("eight pictures per workgroup (8 lanes per picture)" if octl else
-                                 "four pictures per workgroup (16 lanes per picture)" if quad else "one picture per workgroup")
-                                + f", pictures sharded over {world} GPU(s), no collectives"),
+                "parallelism": ({"oct": "eight pictures per workgroup (8 lanes per picture)",
+                                 "quad": "four pictures per workgroup (16 lanes per picture)",
+                                 "rows": "one picture per workgroup"}[layout_name]
+                                + f", {waves_used} wavefronts per workgroup, pictures sharded over {world} GPU(s), no collectives"),
                 "bit_exact_vs_oracle": ok,
             },
             "kernel_ms": {recon_name: ms_recon, "ycbcr_to_rgb_kernel": ms_color},
             "host_frontend": None if host_rate is None else {
                 "macroblocks_per_s_one_thread": host_rate, "stream_bytes_per_picture": stream_bytes / n_distinct,
-                "note": "entropy decode is outside the timed region (inputs resident in HBM)"},
+                "note": "entropy decode is outside the timed region of `value` (inputs resident in HBM); it is inside end_to_end"},
             "roofline": {
                 "bound": "hbm",
                 "kernel": kname,
@@ -278,15 +482,21 @@ def main():
                 "algorithmic_gb_per_launch": mbs_per_step * (bpm if dom_recon else BYTES_PER_MB_COLOR) / 1e9,
                 "bytes_per_macroblock": bpm if dom_recon else BYTES_PER_MB_COLOR,
             },
+            "end_to_end": e2e,
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(params, rec, want_rgb, args.cpu_seconds)
+            cb = cpu_baseline(params, stream, n_distinct, rec, want_rgb, args.cpu_seconds)
+            out["cpu_baseline"] = cb
+            if e2e and "end_to_end" in cb:
+                # not `vs_baseline` (BASELINE.md holds no published number for this metric): the measured ratios
+                e2e["vs_cpu_port_one_thread"] = e2e["value"] / cb["end_to_end"]["value"]
+                e2e["vs_cpu_port_all_cores"] = e2e["value"] / cb["end_to_end"]["all_cores"]["value"]
         print(json.dumps(out), flush=True)
 
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-    if ok is False:
+    if ok is False or (e2e is not None and rank == 0 and not e2e["bit_exact_vs_oracle"]):
         raise SystemExit("bench: GPU output differs from the oracle")
 
 

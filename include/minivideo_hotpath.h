@@ -164,14 +164,9 @@ MVHP_EXPORT int  mvhp_recon_batch_host(mvhp_ctx_t *ctx, const mvhp_stream_params
                                        const void *h_packed, int n_frames,
                                        uint8_t *h_yuv, uint8_t *h_rgb);
 
-/* Measurement helper for bench.py: launches the same work `iters` times on
- * `stream`, bracketed by HIP events recorded on that stream; returns the mean
- * milliseconds per launch of the reconstruction kernel and (when d_rgb is not
- * NULL) of the colour kernel. */
-MVHP_EXPORT int  mvhp_time_recon(mvhp_ctx_t *ctx, const mvhp_stream_params_t *p,
-                                 const void *d_packed, int n_frames,
-                                 uint8_t *d_yuv, uint8_t *d_rgb, void *stream,
-                                 int iters, float *ms_recon, float *ms_color);
+/* What the last reconstruction launch of this context used (speed-only choices of the launcher):
+ * *layout = MVHP_LAYOUT_ROWS/QUAD/OCT, *waves = wavefronts per workgroup.  Either pointer may be NULL. */
+MVHP_EXPORT int  mvhp_last_launch_info(const mvhp_ctx_t *ctx, int *layout, int *waves);
 
 /* 1 (default): the reconstruction kernel converts to RGB in its epilogue when d_rgb is given;
  * 0: a separate colour kernel reads the planes back.  Speed only, never results. */
@@ -192,6 +187,61 @@ MVHP_EXPORT int  mvhp_set_waves_per_picture(mvhp_ctx_t *ctx, int waves);
 #define MVHP_LAYOUT_QUAD 2
 #define MVHP_LAYOUT_OCT  3
 MVHP_EXPORT int  mvhp_set_layout(mvhp_ctx_t *ctx, int layout);
+
+/* ---------------------------------------------------------------------------
+ * Decode engine: the whole split path as one pipelined call --
+ *   host threads entropy-decode pictures (h264.c:76-188 NAL loop, h264_slice.c:1046-1139 macroblock loop)
+ *   into page-locked chunks -> H2D -> batched reconstruction kernel -> D2H into page-locked chunks ->
+ *   `sink` called once per picture, in the order of `order` (export.c:618-767 is what minivideo_decode's sink does).
+ * Pictures are independent, so contexts (one per HIP device; several per device when `contexts` exceeds the
+ * device count, e.g. to exercise the multi-device path on one GPU) pull whole batches from one queue; no collective.
+ * A batch that fails on one context is entropy-decoded again and re-queued once to another context.
+ * ------------------------------------------------------------------------- */
+typedef struct mvhp_engine mvhp_engine_t;
+
+typedef struct mvhp_engine_opts {
+    int32_t contexts;        /* 0 = one per visible HIP device (env MINIVIDEO_GPUS caps it, MINIVIDEO_FAKE_GPUS sets it) */
+    int32_t host_threads;    /* entropy threads; 0 = hardware concurrency (env MINIVIDEO_HOST_THREADS)                */
+    int32_t batch_pictures;  /* pictures per kernel launch; 0 = auto (device fill, memory budget)  (MINIVIDEO_BATCH)  */
+    int32_t chunk_pictures;  /* pictures per H2D / D2H transfer; 0 = auto (~64 MiB of records)                       */
+    int32_t fail_context;    /* test hook: the first batch launched on this context reports a failure; -1 = off       */
+    int32_t first_device;    /* context k runs on HIP device (first_device + k) % device count (one process per GPU:  */
+                             /* contexts = 1, first_device = LOCAL_RANK)                                              */
+    int32_t reserved[2];
+} mvhp_engine_opts_t;
+
+typedef struct mvhp_decode_stats {
+    uint32_t pictures_issued;      /* pictures handed to the entropy stage (a re-queued picture counts twice)       */
+    uint32_t pictures_ok;          /* pictures the sink accepted                                                     */
+    uint32_t pictures_failed;      /* parse / device / sink failures delivered to the sink                           */
+    uint32_t batches;              /* kernel launches                                                                */
+    uint32_t batches_requeued;     /* batches that failed on one context and were re-queued to another               */
+    uint32_t contexts;
+    uint32_t host_threads;
+    uint32_t launches_by_layout[4];/* indexed by MVHP_LAYOUT_*                                                       */
+    uint32_t max_batch_pictures;
+    double   wall_s;               /* whole call                                                                     */
+    double   entropy_busy_s;       /* summed over host threads                                                       */
+    double   h2d_s, kernel_s, d2h_s; /* device-side durations (HIP events), summed over contexts                     */
+    double   sink_s;               /* time inside the sink callback                                                  */
+    uint64_t stream_bytes;         /* NAL bytes entropy-decoded                                                      */
+    uint64_t h2d_bytes, d2h_bytes;
+} mvhp_decode_stats_t;
+
+/* Called on the calling thread, once per picture, in the order of `order`.  rc = MVHP_SUCCESS: yuv (and rgb when
+ * asked for) point into page-locked memory valid during the call.  Otherwise yuv = rgb = NULL and err says why.
+ * Return 1: picture accepted (counts towards `wanted`); 0: not accepted (counts as a failure); -1: stop decoding. */
+typedef int (*mvhp_picture_sink_t)(void *user, int seq, int idr, int rc, const char *err,
+                                   const mvhp_stream_params_t *p, const uint8_t *yuv, const uint8_t *rgb);
+
+MVHP_EXPORT int  mvhp_engine_create(const mvhp_engine_opts_t *opts /* may be NULL */, mvhp_engine_t **out);
+MVHP_EXPORT void mvhp_engine_destroy(mvhp_engine_t *e);
+/* Decode the pictures order[0..n_order) of `s` (IDR indices) until `wanted` of them have been accepted by the sink
+ * (the reference stops after picture_number IDRs, h264.c:173-179: no more pictures than needed are entropy-decoded).
+ * sink may be NULL (every reconstructed picture counts as accepted).  Returns MVHP_SUCCESS when `wanted` pictures
+ * were accepted, or when the list ended after at least one. */
+MVHP_EXPORT int  mvhp_engine_decode(mvhp_engine_t *e, const mvhp_stream_t *s, const int *order, int n_order, int wanted,
+                                    int want_rgb, mvhp_picture_sink_t sink, void *user, mvhp_decode_stats_t *stats);
 
 #ifdef __cplusplus
 }

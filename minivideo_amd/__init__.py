@@ -8,6 +8,7 @@ missing, the calls raise.
 """
 from .hotpath import (  # noqa: F401
     HotPath,
+    Engine,
     StreamParams,
     MiniVideoError,
     lib,
@@ -18,4 +19,4 @@ from .hotpath import (  # noqa: F401
     UNSUPPORTED,
 )
 
-__all__ = ["HotPath", "StreamParams", "MiniVideoError", "lib", "lib_path", "MB_BYTES"]
+__all__ = ["HotPath", "Engine", "StreamParams", "MiniVideoError", "lib", "lib_path", "MB_BYTES"]

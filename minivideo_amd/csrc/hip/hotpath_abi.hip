@@ -7,6 +7,9 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <string>
+
+#include "decode_engine.h"
 #include "minivideo_hotpath.h"
 #include "recon_kernels.h"
 
@@ -53,6 +56,7 @@ struct mvhp_ctx {
     int          fused_color; // 1 = RGB written by the reconstruction kernel's epilogue (default)
     int          n_cus;
     size_t       max_lds;
+    int          last_layout, last_waves;   // what the last reconstruction launch used
     // staging for the host convenience path
     void        *d_packed;
     size_t       d_packed_bytes;
@@ -154,7 +158,7 @@ MVHP_EXPORT int mvhp_set_layout(mvhp_ctx_t *c, int layout)
 MVHP_EXPORT void *mvhp_host_alloc(size_t bytes)
 {
     void *p = nullptr;
-    if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) {
+    if (hipHostMalloc(&p, bytes, hipHostMallocPortable) != hipSuccess) {   // portable: every device may DMA from / to it
         set_err("hipHostMalloc(%zu) failed", bytes);
         return nullptr;
     }
@@ -252,6 +256,8 @@ static int launch_all(mvhp_ctx *c, const mvhp_stream_params_t *p, const void *d_
         a.n_frames = n_frames;
         const int layout = pick_layout(c, p, n_frames);
         const int nw = pick_waves(c, p, n_frames, layout);
+        c->last_layout = layout;
+        c->last_waves = nw;
         if (layout == MVHP_LAYOUT_OCT) {
             HIP_TRY(mvhp::launch_recon_oct(a, nw, st));
         } else if (layout == MVHP_LAYOUT_QUAD) {
@@ -357,47 +363,147 @@ MVHP_EXPORT int mvhp_sync_check(mvhp_ctx_t *c, void *stream)
     return MVHP_SUCCESS;
 }
 
-MVHP_EXPORT int mvhp_time_recon(mvhp_ctx_t *c, const mvhp_stream_params_t *p, const void *d_packed, int n_frames,
-                                uint8_t *d_yuv, uint8_t *d_rgb, void *stream, int iters, float *ms_recon,
-                                float *ms_color)
+MVHP_EXPORT int mvhp_last_launch_info(const mvhp_ctx_t *c, int *layout, int *waves)
 {
-    if (!c || !params_ok(p) || !d_packed || !d_yuv || n_frames <= 0 || iters <= 0) {
-        set_err("mvhp_time_recon: invalid argument");
-        return MVHP_FAILURE;
-    }
-    HIP_TRY(hipSetDevice(c->device));
-    hipStream_t st = stream ? (hipStream_t)stream : c->stream;
-    hipEvent_t e0, e1, e2;
-    HIP_TRY(hipEventCreate(&e0));
-    HIP_TRY(hipEventCreate(&e1));
-    HIP_TRY(hipEventCreate(&e2));
-    float tr = 0.f, tc = 0.f;
-    int rc = MVHP_SUCCESS;
-    for (int i = 0; i < iters && rc == MVHP_SUCCESS; i++) {
-        HIP_TRY(hipEventRecord(e0, st));
-        rc = launch_all(c, p, d_packed, n_frames, d_yuv, d_rgb, st, true, false);
-        HIP_TRY(hipEventRecord(e1, st));
-        if (rc == MVHP_SUCCESS && d_rgb) rc = launch_all(c, p, d_packed, n_frames, d_yuv, d_rgb, st, false, true);
-        HIP_TRY(hipEventRecord(e2, st));
-        HIP_TRY(hipEventSynchronize(e2));
-        float a = 0.f, b = 0.f;
-        HIP_TRY(hipEventElapsedTime(&a, e0, e1));
-        HIP_TRY(hipEventElapsedTime(&b, e1, e2));
-        tr += a;
-        tc += b;
-    }
-    hipEventDestroy(e0);
-    hipEventDestroy(e1);
-    hipEventDestroy(e2);
-    if (ms_recon) *ms_recon = tr / iters;
-    if (ms_color) *ms_color = d_rgb ? tc / iters : 0.f;
-    uint32_t err = 0;
-    HIP_TRY(hipMemcpy(&err, c->d_err, sizeof(err), hipMemcpyDeviceToHost));
-    if (err) {
-        set_err("reconstruction kernel reported error word 0x%x", err);
-        return MVHP_FAILURE;
-    }
-    return rc;
+    if (!c) return MVHP_FAILURE;
+    if (layout) *layout = c->last_layout;
+    if (waves) *waves = c->last_waves;
+    return MVHP_SUCCESS;
 }
 
 } // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------------
+// The decode engine's device table (csrc/host/decode_engine.h): every operation runs on its own HIP stream of the
+// context and blocks the calling engine thread until the device has finished it; durations come from HIP events
+// recorded on that stream.
+// ---------------------------------------------------------------------------------------------------------------
+namespace mvengine {
+struct DevCtx {
+    mvhp_ctx   *c = nullptr;
+    hipStream_t up = nullptr, down = nullptr;
+    hipEvent_t  ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // begin/end per queue: upload, compute, download
+};
+} // namespace mvengine
+
+namespace {
+
+using mvengine::DevCtx;
+
+#define ENG_TRY(expr)                                                                                     \
+    do {                                                                                                  \
+        hipError_t e_ = (expr);                                                                           \
+        if (e_ != hipSuccess) {                                                                           \
+            err = std::string(#expr) + " failed: " + hipGetErrorString(e_);                               \
+            return MVHP_FAILURE;                                                                          \
+        }                                                                                                 \
+    } while (0)
+
+DevCtx *eng_ctx_create(int device, std::string &err)
+{
+    mvhp_ctx_t *c = nullptr;
+    if (mvhp_create(device, &c) != MVHP_SUCCESS) { err = mvhp_last_error(); return nullptr; }
+    DevCtx *d = new DevCtx();
+    d->c = c;
+    bool ok = hipStreamCreateWithFlags(&d->up, hipStreamNonBlocking) == hipSuccess &&
+              hipStreamCreateWithFlags(&d->down, hipStreamNonBlocking) == hipSuccess;
+    for (int i = 0; i < 6 && ok; i++) ok = hipEventCreate(&d->ev[i]) == hipSuccess;
+    if (!ok) {
+        err = "stream / event creation failed on device " + std::to_string(device);
+        for (int i = 0; i < 6; i++) if (d->ev[i]) hipEventDestroy(d->ev[i]);
+        if (d->up) hipStreamDestroy(d->up);
+        if (d->down) hipStreamDestroy(d->down);
+        mvhp_destroy(c);
+        delete d;
+        return nullptr;
+    }
+    return d;
+}
+
+void eng_ctx_destroy(DevCtx *d)
+{
+    if (!d) return;
+    hipSetDevice(d->c->device);
+    hipStreamSynchronize(d->up);
+    hipStreamSynchronize(d->down);
+    for (int i = 0; i < 6; i++) hipEventDestroy(d->ev[i]);
+    hipStreamDestroy(d->up);
+    hipStreamDestroy(d->down);
+    mvhp_destroy(d->c);
+    delete d;
+}
+
+void *eng_dev_alloc(DevCtx *d, size_t bytes)
+{
+    void *p = nullptr;
+    if (hipSetDevice(d->c->device) != hipSuccess || hipMalloc(&p, bytes) != hipSuccess) return nullptr;
+    return p;
+}
+
+void eng_dev_free(DevCtx *d, void *p)
+{
+    hipSetDevice(d->c->device);
+    (void)hipFree(p);
+}
+
+size_t eng_dev_free_bytes(DevCtx *d)
+{
+    size_t fr = 0, tot = 0;
+    if (hipSetDevice(d->c->device) != hipSuccess || hipMemGetInfo(&fr, &tot) != hipSuccess) return 0;
+    return fr;
+}
+
+int eng_copy(DevCtx *d, hipStream_t st, hipEvent_t e0, hipEvent_t e1, void *dst, const void *src, size_t bytes, hipMemcpyKind kind,
+             float *ms, std::string &err)
+{
+    ENG_TRY(hipSetDevice(d->c->device));
+    ENG_TRY(hipEventRecord(e0, st));
+    ENG_TRY(hipMemcpyAsync(dst, src, bytes, kind, st));
+    ENG_TRY(hipEventRecord(e1, st));
+    ENG_TRY(hipEventSynchronize(e1));
+    if (ms) ENG_TRY(hipEventElapsedTime(ms, e0, e1));
+    return MVHP_SUCCESS;
+}
+
+int eng_h2d(DevCtx *d, void *dst, const void *src, size_t bytes, float *ms, std::string &err)
+{
+    return eng_copy(d, d->up, d->ev[0], d->ev[1], dst, src, bytes, hipMemcpyHostToDevice, ms, err);
+}
+
+int eng_d2h(DevCtx *d, void *dst, const void *src, size_t bytes, float *ms, std::string &err)
+{
+    return eng_copy(d, d->down, d->ev[4], d->ev[5], dst, src, bytes, hipMemcpyDeviceToHost, ms, err);
+}
+
+int eng_recon(DevCtx *d, const mvhp_stream_params_t *p, const void *d_packed, int n, uint8_t *d_yuv, uint8_t *d_rgb, float *ms,
+              int *layout, int *waves, std::string &err)
+{
+    mvhp_ctx *c = d->c;
+    if (!params_ok(p) || !d_packed || !d_yuv || n <= 0) { err = "reconstruction: invalid argument"; return MVHP_FAILURE; }
+    ENG_TRY(hipSetDevice(c->device));
+    ENG_TRY(hipEventRecord(d->ev[2], c->stream));
+    const int rc = launch_all(c, p, d_packed, n, d_yuv, d_rgb, c->stream, true, true);
+    if (rc != MVHP_SUCCESS) { err = mvhp_last_error(); return rc; }
+    ENG_TRY(hipEventRecord(d->ev[3], c->stream));
+    uint32_t ew = 0;
+    ENG_TRY(hipMemcpyAsync(&ew, c->d_err, sizeof(ew), hipMemcpyDeviceToHost, c->stream));
+    ENG_TRY(hipStreamSynchronize(c->stream));
+    if (ms) ENG_TRY(hipEventElapsedTime(ms, d->ev[2], d->ev[3]));
+    if (layout) *layout = c->last_layout;
+    if (waves) *waves = c->last_waves;
+    if (ew) {
+        (void)hipMemsetAsync(c->d_err, 0, sizeof(uint32_t), c->stream);
+        err = "reconstruction kernel reported error word (row dependency wait timed out)";
+        return MVHP_FAILURE;
+    }
+    return MVHP_SUCCESS;
+}
+
+const mvengine::DeviceApi g_hip_api = {
+    mvhp_device_count, mvhp_host_alloc, mvhp_host_free, eng_ctx_create, eng_ctx_destroy, eng_dev_alloc, eng_dev_free,
+    eng_dev_free_bytes, eng_h2d, eng_d2h, eng_recon,
+};
+
+} // namespace
+
+const mvengine::DeviceApi &mvhp_hip_device_api() { return g_hip_api; }

@@ -15,13 +15,8 @@
 #include <unistd.h>
 
 #include <algorithm>
-#include <atomic>
-#include <condition_variable>
-#include <deque>
 #include <memory>
-#include <mutex>
 #include <string>
-#include <thread>
 #include <vector>
 
 #include "export.h"
@@ -208,243 +203,49 @@ std::vector<int> select_idrs(const mvhp_stream &s, int picture_number, int mode)
     return sel;
 }
 
-// ---- frame-level work queue over host threads and HIP devices ----
-// A Window is a run of consecutive pictures processed together: their packed records, planes and RGB live in
-// three page-locked buffers (recycled between windows), so entropy threads write records in place, each device
-// DMA-reads its share and DMA-writes results in place, and the writer streams files straight from the buffer.
-struct Picture {
-    int idr = -1;
-    int rc = h264::RC_FAILURE;
-    std::string err;
-    mvhp_stream_params_t params{};
-    size_t packed_off = 0, yuv_off = 0, rgb_off = 0;
-};
+// ---- the sink of minivideo_decode: export.c:618-767 (file naming, format fallbacks, writers) ----
+// The pipeline itself (entropy threads -> H2D -> batched kernels -> D2H, frame-level work queue over every HIP
+// device) is the decode engine, csrc/host/decode_engine.cpp; it calls this once per picture, in stream order.
+struct ExportSink {
+    const MediaFile_t *m = nullptr;
+    int fmt = PICTURE_YUV420;
+    const char *ext = "yuv";
+    bool want_rgb = false;
+    int picture_number = 1;
+    int exported = 0, errors = 0;
+    bool aborted = false;
 
-struct Window {
-    std::vector<Picture> pics;
-    uint8_t *packed = nullptr, *yuv = nullptr, *rgb = nullptr;
-    size_t packed_cap = 0, yuv_cap = 0, rgb_cap = 0;
-    ~Window()
+    static int call(void *user, int seq, int idr, int rc, const char *err, const mvhp_stream_params_t *p, const uint8_t *yuv,
+                    const uint8_t *rgb)
     {
-        mvhp_host_free(packed);
-        mvhp_host_free(yuv);
-        mvhp_host_free(rgb);
-    }
-    bool reserve(size_t pb, size_t yb, size_t rb)
-    {
-        auto grow = [](uint8_t *&p, size_t &cap, size_t need) {
-            if (need <= cap) return true;
-            mvhp_host_free(p);
-            p = (uint8_t *)mvhp_host_alloc(need);
-            cap = p ? need : 0;
-            return p != nullptr;
-        };
-        return grow(packed, packed_cap, pb) && grow(yuv, yuv_cap, yb) && (rb == 0 || grow(rgb, rgb_cap, rb));
-    }
-};
-
-template <class F> void parallel_for(int n, int threads, F f)
-{
-    if (threads < 1) threads = 1;
-    if (threads > n) threads = n;
-    std::atomic<int> next(0);
-    std::vector<std::thread> th;
-    auto body = [&]() { for (int i; (i = next.fetch_add(1)) < n;) f(i); };
-    for (int t = 1; t < threads; t++) th.emplace_back(body);
-    body();
-    for (auto &t : th) t.join();
-}
-
-bool same_params(const mvhp_stream_params_t &a, const mvhp_stream_params_t &b)
-{
-    return a.width_mbs == b.width_mbs && a.height_mbs == b.height_mbs &&
-           a.chroma_qp_index_offset == b.chroma_qp_index_offset &&
-           a.second_chroma_qp_index_offset == b.second_chroma_qp_index_offset;
-}
-
-class Pipeline {
-public:
-    Pipeline(const mvhp_stream &s, std::vector<int> order, bool want_rgb)
-        : s_(s), order_(std::move(order)), want_rgb_(want_rgb)
-    {
-        n_gpus_ = mvhp_device_count();
-        if (const char *e = getenv("MINIVIDEO_GPUS")) { const int v = atoi(e); if (v > 0 && v < n_gpus_) n_gpus_ = v; }
-        host_threads_ = (int)std::thread::hardware_concurrency();
-        if (const char *e = getenv("MINIVIDEO_HOST_THREADS")) { const int v = atoi(e); if (v > 0) host_threads_ = v; }
-        if (host_threads_ < 1) host_threads_ = 1;
-        if (host_threads_ > 64) host_threads_ = 64;
-    }
-    ~Pipeline() { stop(); for (auto *c : ctx_) mvhp_destroy(c); }
-
-    bool start(std::string &err)
-    {
-        if (n_gpus_ <= 0) { err = "no HIP device available: this build has no CPU reconstruction path"; return false; }
-        for (int d = 0; d < n_gpus_; d++) {
-            mvhp_ctx_t *c = nullptr;
-            if (mvhp_create(d, &c) != MVHP_SUCCESS) { err = mvhp_last_error(); return false; }
-            ctx_.push_back(c);
+        (void)seq;
+        ExportSink &x = *static_cast<ExportSink *>(user);
+        if (rc != MVHP_SUCCESS) {
+            log_err("IDR %d: %s", idr, err ? err : "failed");
+            if (++x.errors > 64) { x.aborted = true; return -1; }   // h264.c:181-187
+            return 0;
         }
-        for (int i = 0; i < 3; i++) free_.push_back(std::make_unique<Window>());
-        entropy_thread_ = std::thread([this] { entropy_stage(); });
-        gpu_thread_ = std::thread([this] { gpu_stage(); });
-        return true;
-    }
-    void stop()
-    {
-        {
-            std::lock_guard<std::mutex> l(mu_);
-            stop_ = true;
+        x.errors = 0;
+        // export.c:627-642, 704-708: <file_name>[_k].<ext> in the current working directory
+        std::string name = x.m->file_name;
+        if (x.picture_number > 1) name += "_" + std::to_string(x.exported);
+        name += ".";
+        name += x.ext;
+        const int W = (int)p->width_mbs * 16, H = (int)p->height_mbs * 16;
+        int ok = 0;
+        if (x.fmt == PICTURE_PNG) ok = mvexport::write_png(name, rgb, W, H);
+        else if (x.fmt == PICTURE_BMP) ok = mvexport::write_bmp(name, rgb, W, H);
+        else if (x.fmt == PICTURE_TGA) ok = mvexport::write_tga(name, rgb, W, H);
+        else if (x.fmt == PICTURE_YUV444) ok = mvexport::write_yuv444(name, yuv, W, H);
+        else ok = mvexport::write_yuv420(name, yuv, W, H);
+        if (!ok) {
+            log_err("Unable to write '%s'", name.c_str());
+            x.errors++;
+            return 0;
         }
-        cv_.notify_all();
-        if (entropy_thread_.joinable()) entropy_thread_.join();
-        if (gpu_thread_.joinable()) gpu_thread_.join();
+        x.exported++;
+        return 1;
     }
-    // next finished window in stream order, or nullptr at the end
-    std::unique_ptr<Window> next()
-    {
-        std::unique_lock<std::mutex> l(mu_);
-        cv_.wait(l, [this] { return !done_.empty() || gpu_finished_; });
-        if (done_.empty()) return nullptr;
-        auto w = std::move(done_.front());
-        done_.pop_front();
-        return w;
-    }
-    // hand a consumed window's buffers back
-    void recycle(std::unique_ptr<Window> w)
-    {
-        {
-            std::lock_guard<std::mutex> l(mu_);
-            free_.push_back(std::move(w));
-        }
-        cv_.notify_all();
-    }
-
-private:
-    int window_frames(const mvhp_stream_params_t &p) const
-    {
-        const size_t pb = mvhp_packed_frame_bytes(&p);
-        long f = (long)((size_t)256 << 20) / (long)(pb ? pb : 1);
-        if (f < 2 * n_gpus_) f = 2 * n_gpus_;
-        if (f < 4) f = 4;
-        if (f > 256) f = 256;
-        return (int)f;
-    }
-    void entropy_stage()
-    {
-        size_t pos = 0;
-        while (pos < order_.size()) {
-            std::unique_ptr<Window> w;
-            {
-                std::unique_lock<std::mutex> l(mu_);
-                cv_.wait(l, [this] { return stop_ || !free_.empty(); });
-                if (stop_) break;
-                w = std::move(free_.front());
-                free_.pop_front();
-            }
-            mvhp_stream_params_t p0{};
-            int wf = 16;
-            for (size_t k = pos; k < order_.size(); k++)
-                if (mvhp_stream_params(&s_, order_[k], &p0) == MVHP_SUCCESS) { wf = window_frames(p0); break; }
-            const size_t end = std::min(order_.size(), pos + (size_t)wf);
-            w->pics.assign(end - pos, Picture());
-            size_t pb = 0, yb = 0, rb = 0;
-            for (size_t k = pos; k < end; k++) {
-                Picture &pic = w->pics[k - pos];
-                pic.idr = order_[k];
-                if (mvhp_stream_params(&s_, pic.idr, &pic.params) != MVHP_SUCCESS) {
-                    pic.rc = h264::RC_FAILURE;
-                    pic.err = "parameter sets missing";
-                    continue;
-                }
-                pic.rc = h264::RC_UNSUPPORTED; // "not parsed yet"
-                pic.packed_off = pb; pic.yuv_off = yb; pic.rgb_off = rb;
-                pb += mvhp_packed_frame_bytes(&pic.params);
-                yb += mvhp_yuv_frame_bytes(&pic.params);
-                if (want_rgb_) rb += mvhp_rgb_frame_bytes(&pic.params);
-            }
-            if (!w->reserve(pb, yb, rb)) {
-                for (Picture &pic : w->pics) { pic.rc = h264::RC_FAILURE; pic.err = "out of page-locked host memory"; }
-            } else {
-                parallel_for((int)w->pics.size(), host_threads_, [&](int i) {
-                    Picture &pic = w->pics[i];
-                    if (pic.rc != h264::RC_UNSUPPORTED) return;
-                    pic.rc = s_.decode_packed(pic.idr, w->packed + pic.packed_off, mvhp_packed_frame_bytes(&pic.params), pic.err);
-                });
-            }
-            pos = end;
-            {
-                std::lock_guard<std::mutex> l(mu_);
-                parsed_.push_back(std::move(w));
-            }
-            cv_.notify_all();
-        }
-        {
-            std::lock_guard<std::mutex> l(mu_);
-            entropy_finished_ = true;
-        }
-        cv_.notify_all();
-    }
-    void gpu_stage()
-    {
-        for (;;) {
-            std::unique_ptr<Window> w;
-            {
-                std::unique_lock<std::mutex> l(mu_);
-                cv_.wait(l, [this] { return stop_ || !parsed_.empty() || entropy_finished_; });
-                if (stop_ || parsed_.empty()) break;
-                w = std::move(parsed_.front());
-                parsed_.pop_front();
-            }
-            // maximal runs of consecutive parsed pictures with identical stream parameters are contiguous in the
-            // window buffers; each run is dealt out to the devices in contiguous shares
-            const int n_pics = (int)w->pics.size();
-            int a = 0;
-            while (a < n_pics) {
-                if (w->pics[a].rc != h264::RC_SUCCESS) { a++; continue; }
-                int b = a + 1;
-                while (b < n_pics && w->pics[b].rc == h264::RC_SUCCESS && same_params(w->pics[a].params, w->pics[b].params)) b++;
-                const int n = b - a;
-                const int parts = std::min(n, n_gpus_);
-                std::atomic<int> next_part(0);
-                auto work = [&](int dev) {
-                    for (int part; (part = next_part.fetch_add(1)) < parts;) {
-                        const int lo = a + (int)((long)n * part / parts), hi = a + (int)((long)n * (part + 1) / parts);
-                        const Picture &first = w->pics[lo];
-                        const int rc = mvhp_recon_batch_host(ctx_[dev], &first.params, w->packed + first.packed_off, hi - lo,
-                                                             w->yuv + first.yuv_off, want_rgb_ ? w->rgb + first.rgb_off : nullptr);
-                        if (rc != MVHP_SUCCESS)
-                            for (int i = lo; i < hi; i++) { w->pics[i].rc = h264::RC_FAILURE; w->pics[i].err = mvhp_last_error(); }
-                    }
-                };
-                std::vector<std::thread> th;
-                for (int d = 1; d < parts; d++) th.emplace_back(work, d);
-                work(0);
-                for (auto &t : th) t.join();
-                a = b;
-            }
-            {
-                std::lock_guard<std::mutex> l(mu_);
-                done_.push_back(std::move(w));
-            }
-            cv_.notify_all();
-        }
-        {
-            std::lock_guard<std::mutex> l(mu_);
-            gpu_finished_ = true;
-        }
-        cv_.notify_all();
-    }
-
-    const mvhp_stream &s_;
-    std::vector<int> order_;
-    bool want_rgb_;
-    int n_gpus_ = 0, host_threads_ = 1;
-    std::vector<mvhp_ctx_t *> ctx_;
-    std::thread entropy_thread_, gpu_thread_;
-    std::mutex mu_;
-    std::condition_variable cv_;
-    std::deque<std::unique_ptr<Window>> free_, parsed_, done_;
-    bool stop_ = false, entropy_finished_ = false, gpu_finished_ = false;
 };
 
 } // namespace
@@ -585,43 +386,24 @@ minivideo_EXPORT int minivideo_decode(MediaFile_t *m, const char *output_directo
     else if (fmt == PICTURE_TGA) ext = "tga";
     const bool want_rgb = (fmt == PICTURE_PNG || fmt == PICTURE_BMP || fmt == PICTURE_TGA);
 
-    Pipeline pipe(s, order, want_rgb);
-    if (!pipe.start(err)) { log_err("%s", err.c_str()); return FAILURE; }
-
-    int exported = 0, errors = 0, retcode = FAILURE;
-    bool running = true;
-    while (running) {
-        std::unique_ptr<Window> w = pipe.next();
-        if (!w) break;
-        for (Picture &pic : w->pics) {
-            if (pic.rc != h264::RC_SUCCESS) {
-                log_err("IDR %d: %s", pic.idr, pic.err.c_str());
-                if (++errors > 64) { running = false; retcode = FAILURE; break; } // h264.c:181-187
-                continue;
-            }
-            errors = 0;
-            // export.c:627-642, 704-708: <file_name>[_k].<ext> in the current working directory
-            std::string name = m->file_name;
-            if (picture_number > 1) name += "_" + std::to_string(exported);
-            name += ".";
-            name += ext;
-            const int W = (int)pic.params.width_mbs * 16, H = (int)pic.params.height_mbs * 16;
-            int ok = 0;
-            const uint8_t *yuv = w->yuv + pic.yuv_off, *rgb = want_rgb ? w->rgb + pic.rgb_off : nullptr;
-            if (fmt == PICTURE_PNG) ok = mvexport::write_png(name, rgb, W, H);
-            else if (fmt == PICTURE_BMP) ok = mvexport::write_bmp(name, rgb, W, H);
-            else if (fmt == PICTURE_TGA) ok = mvexport::write_tga(name, rgb, W, H);
-            else if (fmt == PICTURE_YUV444) ok = mvexport::write_yuv444(name, yuv, W, H);
-            else ok = mvexport::write_yuv420(name, yuv, W, H);
-            if (!ok) { log_err("Unable to write '%s'", name.c_str()); errors++; continue; }
-            exported++;
-            if (exported == wanted) { retcode = SUCCESS; running = false; break; } // h264.c:173-179
-        }
-        if (running) pipe.recycle(std::move(w));
-    }
-    pipe.stop();
-    if (retcode != SUCCESS && exported > 0 && errors <= 64) retcode = SUCCESS; // stream ended after the last good IDR
-    return retcode;
+    mvhp_engine_t *eng = nullptr;
+    if (mvhp_engine_create(nullptr, &eng) != MVHP_SUCCESS) return FAILURE;   // (the reason has been printed)
+    ExportSink sink;
+    sink.m = m;
+    sink.fmt = fmt;
+    sink.ext = ext;
+    sink.want_rgb = want_rgb;
+    sink.picture_number = picture_number;
+    mvhp_decode_stats_t st;
+    // decodes in order until `wanted` pictures have been written (h264.c:173-179) or 64 errors in a row (h264.c:181-187)
+    (void)mvhp_engine_decode(eng, &s, order.data(), (int)order.size(), wanted, want_rgb ? 1 : 0, ExportSink::call, &sink, &st);
+    mvhp_engine_destroy(eng);
+    if (getenv("MINIVIDEO_STATS"))
+        fprintf(stderr, "[minivideo] decode: %u pictures entropy-decoded, %u written, %u failed, %u launches (largest %u pictures), "
+                        "%u contexts, %u host threads, %.3f s\n", st.pictures_issued, st.pictures_ok, st.pictures_failed, st.batches,
+                st.max_batch_pictures, st.contexts, st.host_threads, st.wall_s);
+    if (sink.aborted) return FAILURE;
+    return sink.exported > 0 ? SUCCESS : FAILURE;   // all wanted pictures, or the stream ended after the last good IDR
 }
 
 minivideo_EXPORT int minivideo_extract(MediaFile_t *m, const char *output_directory, const bool extract_audio,

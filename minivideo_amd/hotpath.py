@@ -84,8 +84,8 @@ def lib():
     L.mvhp_recon_batch_host.argtypes = [vp, pp, vp, i32, vp, vp]
     L.mvhp_sync_check.restype = i32
     L.mvhp_sync_check.argtypes = [vp, vp]
-    L.mvhp_time_recon.restype = i32
-    L.mvhp_time_recon.argtypes = [vp, pp, vp, i32, vp, vp, vp, i32, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.mvhp_last_launch_info.restype = i32
+    L.mvhp_last_launch_info.argtypes = [vp, C.POINTER(i32), C.POINTER(i32)]
     if hasattr(L, "mvhp_stream_open"):
         L.mvhp_stream_open.restype = i32
         L.mvhp_stream_open.argtypes = [vp, sz, C.POINTER(vp)]
@@ -172,10 +172,88 @@ class HotPath:
         if self._L.mvhp_sync_check(self._h, stream) != SUCCESS:
             raise _err(self._L, "mvhp_sync_check")
 
-    def time_recon(self, params, d_packed, n_frames, d_yuv, d_rgb=None, stream=None, iters=10):
-        a, b = C.c_float(0), C.c_float(0)
-        rc = self._L.mvhp_time_recon(self._h, C.byref(params), d_packed, int(n_frames), d_yuv, d_rgb, stream,
-                                     int(iters), C.byref(a), C.byref(b))
-        if rc != SUCCESS:
-            raise _err(self._L, "mvhp_time_recon")
-        return a.value, b.value
+    def last_launch(self):
+        """(layout name, waves per workgroup) of the last reconstruction launch -- speed-only choices of the launcher."""
+        lay, nw = C.c_int(0), C.c_int(0)
+        self._L.mvhp_last_launch_info(self._h, C.byref(lay), C.byref(nw))
+        return {0: "auto", 1: "rows", 2: "quad", 3: "oct"}.get(lay.value, "?"), nw.value
+
+
+# ---------------------------------------------------------------------------
+# decode engine (mvhp_engine_*): stream bytes -> reconstructed pictures, pipelined
+# ---------------------------------------------------------------------------
+class EngineOpts(C.Structure):
+    """mvhp_engine_opts_t"""
+    _fields_ = [("contexts", C.c_int32), ("host_threads", C.c_int32), ("batch_pictures", C.c_int32),
+                ("chunk_pictures", C.c_int32), ("fail_context", C.c_int32), ("first_device", C.c_int32),
+                ("reserved", C.c_int32 * 2)]
+
+
+class DecodeStats(C.Structure):
+    """mvhp_decode_stats_t"""
+    _fields_ = [("pictures_issued", C.c_uint32), ("pictures_ok", C.c_uint32), ("pictures_failed", C.c_uint32),
+                ("batches", C.c_uint32), ("batches_requeued", C.c_uint32), ("contexts", C.c_uint32),
+                ("host_threads", C.c_uint32), ("launches_by_layout", C.c_uint32 * 4), ("max_batch_pictures", C.c_uint32),
+                ("wall_s", C.c_double), ("entropy_busy_s", C.c_double), ("h2d_s", C.c_double), ("kernel_s", C.c_double),
+                ("d2h_s", C.c_double), ("sink_s", C.c_double), ("stream_bytes", C.c_uint64), ("h2d_bytes", C.c_uint64),
+                ("d2h_bytes", C.c_uint64)]
+
+    def as_dict(self):
+        d = {}
+        for name, _ in self._fields_:
+            v = getattr(self, name)
+            d[name] = list(v) if hasattr(v, "__len__") else v
+        return d
+
+
+SINK_T = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_char_p, C.POINTER(StreamParams),
+                     C.POINTER(C.c_uint8), C.POINTER(C.c_uint8))
+
+
+class Engine:
+    """mvhp_engine_t: host entropy threads -> H2D -> batched kernels -> D2H -> sink, over every context."""
+
+    def __init__(self, contexts=0, host_threads=0, batch_pictures=0, chunk_pictures=0, fail_context=-1, first_device=0):
+        self._L = L = lib()
+        L.mvhp_engine_create.restype = C.c_int
+        L.mvhp_engine_create.argtypes = [C.POINTER(EngineOpts), C.POINTER(C.c_void_p)]
+        L.mvhp_engine_destroy.restype = None
+        L.mvhp_engine_destroy.argtypes = [C.c_void_p]
+        L.mvhp_engine_decode.restype = C.c_int
+        L.mvhp_engine_decode.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, SINK_T,
+                                         C.c_void_p, C.POINTER(DecodeStats)]
+        o = EngineOpts(contexts, host_threads, batch_pictures, chunk_pictures, fail_context, first_device)
+        h = C.c_void_p()
+        if L.mvhp_engine_create(C.byref(o), C.byref(h)) != SUCCESS:
+            raise MiniVideoError("mvhp_engine_create failed (no HIP device? there is no CPU reconstruction path)")
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.mvhp_engine_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def decode(self, stream_handle, order, wanted=None, want_rgb=False, sink=None):
+        """sink(seq, idr, rc, err, params, yuv ndarray | None, rgb ndarray | None) -> 1 accept / 0 reject / -1 stop;
+        the arrays are views of page-locked memory valid only during the call.  Returns (rc, stats dict)."""
+        order = (C.c_int * len(order))(*order)
+        st = DecodeStats()
+
+        def _cb(user, seq, idr, rc, err, p, yuv, rgb):
+            if sink is None:
+                return 1 if rc == SUCCESS else 0
+            pr = p.contents
+            y = np.ctypeslib.as_array(yuv, shape=(pr.yuv_bytes,)) if yuv else None
+            r = np.ctypeslib.as_array(rgb, shape=(pr.rgb_bytes,)) if rgb else None
+            return int(sink(seq, idr, rc, err.decode() if err else "", pr, y, r))
+
+        cb = SINK_T(_cb) if sink is not None else C.cast(None, SINK_T)
+        rc = self._L.mvhp_engine_decode(self._h, stream_handle, order, len(order), len(order) if wanted is None else wanted,
+                                        1 if want_rgb else 0, cb, None, C.byref(st))
+        return rc, st.as_dict()
