@@ -61,7 +61,7 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=5.0, help="budget of each of the four CPU baseline legs")
     ap.add_argument("--e2e-pictures", type=int, default=-1,
-                    help="pictures of the end-to-end leg, in total over the ranks (-1: 512, or P with --strong; 0: skip)")
+                    help="pictures of the end-to-end leg, in total over the ranks (-1: 2048 = two launches of the four-picture kernel, or P with --strong; 0: skip)")
     ap.add_argument("--e2e-batch", type=int, default=0, help="pictures per launch in the end-to-end leg (0: engine default)")
     ap.add_argument("--host-threads", type=int, default=0, help="entropy threads per rank (0: host cores / ranks)")
     return ap.parse_args()
@@ -105,6 +105,18 @@ def measured_traffic(args, fused, kernel, frames):
     return None, None
 
 
+def host_cores():
+    """Cores this process may use: hardware threads cut down to the container's CPU quota (cgroup cpu.max)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, -(-int(q) // int(p))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -137,7 +149,7 @@ def cpu_baseline(params, stream, n_distinct, rec, want_rgb, budget_s):
     from minivideo_amd import lib
     from oracle import loader
     L = lib()
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     h = C.c_void_p()
     have_stream = stream is not None and L.mvhp_stream_open(stream.ctypes.data, stream.size, C.byref(h)) == 1
     mbs = params.mbs
@@ -177,6 +189,7 @@ def cpu_baseline(params, stream, n_distinct, rec, want_rgb, budget_s):
                   f"the stages of the GPU step (packed records -> planes" + (" -> RGB)" if want_rgb else ")"),
         "cpu_model": cpu_model(),
         "host_cores": cores,
+        "hardware_threads": os.cpu_count(),
         "all_cores": {"value": rN, "cores": cores, "sample": f"{nN} pictures, {dN:.1f} s, one picture per thread"},
     }
     if have_stream:
@@ -199,7 +212,7 @@ def end_to_end(args, params, stream, n_distinct, rec, want_rgb, total, rank, wor
     from minivideo_amd import Engine, lib
     from minivideo_amd.dist import shard
     L = lib()
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     threads = args.host_threads or max(1, cores // world)
     big = repeat_stream(stream, n_distinct, total)
     h = C.c_void_p()
@@ -410,7 +423,7 @@ def main():
     torch.cuda.empty_cache()
 
     # ---- end to end (stream bytes -> host planes), every rank on its share ----
-    e2e_total = args.e2e_pictures if args.e2e_pictures >= 0 else (args.strong or 512)
+    e2e_total = args.e2e_pictures if args.e2e_pictures >= 0 else (args.strong or 2048)
     e2e = None
     if e2e_total >= world and stream is not None:
         e2e = end_to_end(args, params, stream, n_distinct, rec, want_rgb, e2e_total, rank, world, local_rank, dist, dev)

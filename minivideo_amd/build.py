@@ -50,23 +50,29 @@ def build_product(force=False):
         if force or _newer(o, [s] + hdrs):
             _run(["g++", "-O2", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-pthread", "-c", s, "-o", o] + inc)
         objs.append(o)
-    for s in hip_src:   # device + host objects of the kernels, gfx950 only
-        o = os.path.join(objdir, os.path.basename(s)[:-4] + ".hip.o")
-        if force or _newer(o, [s] + hdrs):
-            _run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wno-unused-value",
-                  "-c", s, "-o", o] + inc)
-        objs.append(o)
-    # the quad kernel keeps its record prefetch in registers that only inline assembly names: check, on the ISA these
-    # very flags produce, that the compiler's code stays off them while loads are in flight (tools/check_prefetch_hazard.py)
+    # The batch kernels keep their record prefetch in registers that only inline assembly names: check, on the ISA of
+    # THE compile whose object is linked (-save-temps=obj keeps its .s), that the compiler's code stays off them while
+    # loads are in flight and that the hand-padded hazards are in place (tools/check_prefetch_hazard.py).
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import check_prefetch_hazard
-    for name in ("recon_quad", "recon_oct"):
-        src = os.path.join(CSRC, "hip", name + ".hip")
-        asm = os.path.join(objdir, name + ".s")
-        if force or _newer(asm, [src] + hdrs):
-            _run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wno-unused-value",
-                  "--cuda-device-only", "-S", src, "-o", asm] + inc)
-        check_prefetch_hazard.main(asm)
+    checked = ("recon_quad", "recon_oct")
+    for s in hip_src:   # device + host objects of the kernels, gfx950 only
+        base = os.path.basename(s)[:-4]
+        o = os.path.join(objdir, base + ".hip.o")
+        tmpd = os.path.join(objdir, "temps_" + base)
+        asm = os.path.join(tmpd, base + "-hip-amdgcn-amd-amdhsa-gfx950.s")
+        need_asm = base in checked
+        if force or _newer(o, [s] + hdrs) or (need_asm and not os.path.exists(asm)):
+            cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wno-unused-value"]
+            if need_asm:
+                os.makedirs(tmpd, exist_ok=True)
+                o_tmp = os.path.join(tmpd, base + ".hip.o")
+                _run(cmd + ["-save-temps=obj", "-c", s, "-o", o_tmp] + inc)
+                check_prefetch_hazard.main(asm)   # raises HazardError: the object is not installed then
+                os.replace(o_tmp, o)
+            else:
+                _run(cmd + ["-c", s, "-o", o] + inc)
+        objs.append(o)
     _run([HIPCC, "--offload-arch=gfx950", "--hip-link", "-shared", "-fPIC", "-pthread", "-o", LIB] + objs)
     blob = open(LIB, "rb").read()
     if b"amdgcn-amd-amdhsa--gfx950" not in blob:

@@ -407,7 +407,9 @@ DevCtx *eng_ctx_create(int device, std::string &err)
     d->c = c;
     bool ok = hipStreamCreateWithFlags(&d->up, hipStreamNonBlocking) == hipSuccess &&
               hipStreamCreateWithFlags(&d->down, hipStreamNonBlocking) == hipSuccess;
-    for (int i = 0; i < 6 && ok; i++) ok = hipEventCreate(&d->ev[i]) == hipSuccess;
+    // blocking-sync events: the engine's copy / launch threads sleep in hipEventSynchronize instead of spinning on a core
+    // the entropy threads could use
+    for (int i = 0; i < 6 && ok; i++) ok = hipEventCreateWithFlags(&d->ev[i], hipEventBlockingSync) == hipSuccess;
     if (!ok) {
         err = "stream / event creation failed on device " + std::to_string(device);
         for (int i = 0; i < 6; i++) if (d->ev[i]) hipEventDestroy(d->ev[i]);
@@ -486,6 +488,7 @@ int eng_recon(DevCtx *d, const mvhp_stream_params_t *p, const void *d_packed, in
     if (rc != MVHP_SUCCESS) { err = mvhp_last_error(); return rc; }
     ENG_TRY(hipEventRecord(d->ev[3], c->stream));
     uint32_t ew = 0;
+    ENG_TRY(hipEventSynchronize(d->ev[3]));   // (sleeps: blocking-sync event)
     ENG_TRY(hipMemcpyAsync(&ew, c->d_err, sizeof(ew), hipMemcpyDeviceToHost, c->stream));
     ENG_TRY(hipStreamSynchronize(c->stream));
     if (ms) ENG_TRY(hipEventElapsedTime(ms, d->ev[2], d->ev[3]));

@@ -46,6 +46,26 @@ int env_int(const char *name, int dflt)
     return atoi(e);
 }
 
+// Host cores this process may actually use: the hardware thread count, cut down to the CPU-time quota of the
+// container (cgroup v2 cpu.max / v1 cfs quota) -- a box of 256 hardware threads often grants 16 CPUs per GPU, and
+// 256 entropy threads sharing 16 CPUs only thrash.
+int effective_cores()
+{
+    int n = (int)std::thread::hardware_concurrency();
+    if (n < 1) n = 1;
+    long quota = -1, period = -1;
+    if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char q[32] = "";
+        if (fscanf(f, "%31s %ld", q, &period) == 2 && strcmp(q, "max") != 0) quota = atol(q);
+        fclose(f);
+    } else {
+        if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (fscanf(g, "%ld", &quota) != 1) quota = -1; fclose(g); }
+        if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(g, "%ld", &period) != 1) period = -1; fclose(g); }
+    }
+    if (quota > 0 && period > 0) n = std::min<long>(n, std::max<long>(1, (quota + period - 1) / period));
+    return n;
+}
+
 bool same_params(const mvhp_stream_params_t &a, const mvhp_stream_params_t &b)
 {
     return a.width_mbs == b.width_mbs && a.height_mbs == b.height_mbs &&
@@ -218,7 +238,7 @@ bool Engine::init(const mvhp_engine_opts_t *opts, std::string &err)
     }
     if (n_ctx > 64) n_ctx = 64;
     host_threads_ = opts_.host_threads > 0 ? opts_.host_threads : env_int("MINIVIDEO_HOST_THREADS", 0);
-    if (host_threads_ <= 0) host_threads_ = (int)std::thread::hardware_concurrency();
+    if (host_threads_ <= 0) host_threads_ = effective_cores();
     if (host_threads_ < 1) host_threads_ = 1;
     if (host_threads_ > 256) host_threads_ = 256;
     if (opts_.batch_pictures <= 0) opts_.batch_pictures = env_int("MINIVIDEO_BATCH", 0);

@@ -12,6 +12,14 @@
 
 using namespace h264;
 
+// A slice cannot be smaller than its picture allows: a CAVLC macroblock takes at least one bit, a CABAC one rarely
+// less than a quarter of a bit -- eight macroblocks per payload bit is far outside anything an encoder emits.  Checked
+// before any picture-sized buffer is reserved, so a 100-byte file announcing 1024 x 1024 macroblocks costs nothing.
+static bool slice_can_hold_picture(const Sps &sps, size_t nal_size)
+{
+    return (uint64_t)nal_size * 64u >= (uint64_t)sps.width_mbs * (uint64_t)sps.height_map_units;
+}
+
 int mvhp_stream::build(std::string &err)
 {
     if (index_annexb(data, size, samples) != RC_SUCCESS) { err = "no NAL unit found in the bitstream"; return RC_FAILURE; }
@@ -41,7 +49,8 @@ int mvhp_stream::build(std::string &err)
             if (pid < 256 && pps_tab[pid].valid && sps_tab[pps_tab[pid].sps_id].valid) {
                 idr.pps = pps_tab[pid];
                 idr.sps = sps_tab[idr.pps.sps_id];
-                idr.ok = true;
+                idr.ok = slice_can_hold_picture(idr.sps, s.nal_size);
+                if (!idr.ok) idr.why = "slice NAL too small for the picture size of its SPS";
             } else {
                 idr.why = "slice refers to a parameter set that was not (successfully) received";
             }
@@ -102,7 +111,8 @@ int mvhp_stream::build_mp4(std::string &err)
                 if (pid < 256 && pps_tab[pid].valid && sps_tab[pps_tab[pid].sps_id].valid) {
                     idr.pps = pps_tab[pid];
                     idr.sps = sps_tab[idr.pps.sps_id];
-                    idr.ok = true;
+                    idr.ok = slice_can_hold_picture(idr.sps, len);
+                    if (!idr.ok) idr.why = "slice NAL too small for the picture size of its SPS";
                 } else {
                     idr.why = "slice refers to a parameter set that was not (successfully) received";
                 }

@@ -146,3 +146,25 @@ def test_truncated_slice_fails_cleanly():
     with Stream(np.frombuffer(cut, np.uint8)) as s:
         rc, _ = s.packed(0)
         assert rc != 1
+
+
+def test_tiny_stream_announcing_a_huge_picture_is_rejected_before_allocation():
+    """a ~100-byte stream whose SPS says 1024 x 1024 macroblocks must not make anyone reserve
+    picture-sized (838 MB) buffers: the IDR is marked undecodable when the stream is opened."""
+    import ctypes as C
+    data = np.fromfile(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "kat_cavlc_2mb.264"), np.uint8)
+    # rewrite the SPS: same syntax as Appendix A, pic_width_in_mbs_minus1 = pic_height_in_map_units_minus1 = 1023
+    bits = "01000010" + "00000000" + "00011110"          # profile 66, constraint flags, level 30
+    ue = lambda v: "0" * (len(bin(v + 1)) - 3) + bin(v + 1)[2:]
+    bits += ue(0) + ue(0) + ue(0) + ue(0) + ue(0) + "0" + ue(1023) + ue(1023) + "1" + "1" + "0" + "0" + "1"
+    bits += "0" * (-len(bits) % 8)
+    sps = bytes(int(bits[i:i + 8], 2) for i in range(0, len(bits), 8))
+    raw = bytes(data)
+    a = raw.index(b"\x00\x00\x00\x01\x67") + 5
+    b = raw.index(b"\x00\x00\x00\x01\x68")
+    crafted = np.frombuffer(raw[:a] + sps + raw[b:], np.uint8)
+    with Stream(crafted) as s:
+        assert s.ok and s.idr_count == 1
+        assert s.params(0) is None            # no parameters handed out: nobody sizes a buffer from this SPS
+        rc, _ = s.packed(0)
+        assert rc != 1

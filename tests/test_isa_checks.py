@@ -53,10 +53,24 @@ def test_checker_catches_violations(tmp_path):
     loads = [i for i in range(k0, k1) if "global_load_dwordx4 v[120:123]" in lines[i]]
     at = loads[-1] + 2          # behind the #ASMEND of the block
     for inject in ("\tv_mov_b32_e32 v101, v1",
-                   "\t;;#ASMSTART\n\tglobal_store_dwordx4 v1, v[2:5], s[0:1]\n\t;;#ASMEND",
+                   "\t;;#ASMSTART\n\ts_nop 4\n\tglobal_store_dwordx4 v1, v[2:5], s[0:1]\n\ts_nop 1\n\t;;#ASMEND",
                    "\tscratch_load_dword v1, off, off"):
         bad = lines[:at] + inject.split("\n") + lines[at:]
         p = tmp_path / "bad.s"
         p.write_text("\n".join(bad))
-        with pytest.raises(AssertionError):
+        with pytest.raises(chk.HazardError):
             chk.main(str(p))
+    # (d) the hand-padded hazards: the round-1 GPU memory fault was a vector-memory instruction reading
+    # its scalar base right behind the v_readlane that wrote it.  Drop the wait states in front of the loop's prefetch
+    # block, or behind a 128-bit store, and the checker must refuse the ISA.
+    blk0 = max(i for i in range(k0, loads[-1]) if "#ASMSTART" in lines[i])
+    nop = next(i for i in range(blk0, loads[-1]) if re.match(r"\s*s_nop 4", lines[i]))
+    p = tmp_path / "bad.s"
+    p.write_text("\n".join(lines[:nop] + lines[nop + 1:]))
+    with pytest.raises(chk.HazardError, match="wait states in front"):
+        chk.main(str(p))
+    st = next(i for i in range(k0, k1) if re.match(r"\s*global_store_dwordx4", lines[i]) and re.match(r"\s*s_nop 4", lines[i - 1]))
+    assert re.match(r"\s*s_nop 1", lines[st + 1])   # (an inline-assembly store of the strip flush)
+    p.write_text("\n".join(lines[:st + 1] + lines[st + 2:]))
+    with pytest.raises(chk.HazardError, match="wait states behind"):
+        chk.main(str(p))

@@ -12,7 +12,12 @@ INC="-I$R/include -I$R/minivideo_amd/csrc/hip -I$R/minivideo_amd/csrc/host"
 OBJS=""
 for s in $R/minivideo_amd/csrc/hip/*.hip; do
   o=$O/$(basename $s).o
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -Wno-unused-value "$@" -c $s -o $o $INC
+  b=$(basename $s .hip)
+  mkdir -p $O/temps_$b
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -Wno-unused-value "$@" -save-temps=obj -c $s -o $O/temps_$b/$b.hip.o $INC
+  cp $O/temps_$b/$b.hip.o $o
+  # the same ISA check as the product build, on the ISA these flags produce (a variant that fails it is not a measurement)
+  case $b in recon_quad|recon_oct) python3 $R/tools/check_prefetch_hazard.py $O/temps_$b/$b-hip-amdgcn-amd-amdhsa-gfx950.s > $O/$b.check || { echo "ISA CHECK FAILED for variant $NAME ($b)"; exit 1; } ;; esac
   OBJS="$OBJS $o"
 done
 HOST=$(ls $R/minivideo_amd/build/*.o | grep -v "\.hip\.o")

@@ -3,10 +3,25 @@
 names (the compiler is limited to v0-v99 by amdgpu_num_vgpr): (a) no compiler-generated instruction may touch them;
 (b) the guarded wait in front of their use is `s_waitcnt vmcnt(N)` with N = the number of stores a full-strip step
 issues behind the prefetch, so exactly N asm stores must sit in the macroblock loop; (c) no scratch access (register
-spill = a vector-memory operation the counted waits do not know about) may sit in that loop.
+spill = a vector-memory operation the counted waits do not know about) may sit in that loop; (d) every inline-assembly
+block that issues vector-memory instructions pads the hazards inline assembly hides from the compiler: >= 5 wait states
+(`s_nop 4`) in front of its first vector-memory instruction -- the scalar base may have been written by a `v_readlane`
+right in front of the block, and a vector-memory read of a VALU-written SGPR needs that distance (the round-1 GPU memory
+fault) -- and >= 2 wait states (`s_nop 1`) behind a 128-bit store before its data registers may be rewritten.
+The oct kernel's prefetch registers are v216-v247.
+Violations raise HazardError (never a bare assert: the check must survive `python -O`).
 usage: check_prefetch_hazard.py file.s"""
 import re
 import sys
+
+
+class HazardError(Exception):
+    pass
+
+
+def require(cond, *info):
+    if not cond:
+        raise HazardError(info)
 
 
 def regs(tok):
@@ -44,18 +59,37 @@ def check(L, name):
         if in_asm:
             if re.match(r'\s+global_load_dwordx4', l):
                 asm_loads.append(i)
-                assert regs(l.split(',')[0]) <= PREFETCH, (name, l)
+                require(regs(l.split(',')[0]) <= PREFETCH, name, l)
             elif re.match(r'\s+global_store', l):
                 asm_stores_at.append(i)
-                assert not (regs(l) & PREFETCH), (name, l)
+                require(not (regs(l) & PREFETCH), name, l)
         elif regs(l) & PREFETCH:
             touched.append((i, l))
-    assert len(asm_loads) == 2 * n_block, (name, len(asm_loads))      # one block in the prologue, one in the loop
+    require(len(asm_loads) == 2 * n_block, name, len(asm_loads))      # one block in the prologue, one in the loop
+    # (d) hazard padding inside every asm block that touches vector memory
+    blk = None
+    for i, raw in enumerate(L):
+        if '#ASMSTART' in raw:
+            blk = []
+        elif '#ASMEND' in raw and blk is not None:
+            vm = [k for k, t in enumerate(blk) if re.match(r'\s*global_(load|store)', t)]
+            if vm:
+                pad = [int(m.group(1)) for t in blk[:vm[0]] for m in [re.match(r'\s*s_nop\s+(\d+)', t)] if m]
+                require(pad and max(pad) >= 4, name, 'vector-memory asm without 5 wait states in front (v_readlane -> VMEM base hazard)', i)
+                for k in vm:
+                    if re.match(r'\s*global_store_dwordx4', blk[k]):
+                        nxt = blk[k + 1] if k + 1 < len(blk) else ''
+                        require(re.match(r'\s*s_nop\s+[1-9]', nxt), name, '128-bit asm store without 2 wait states behind it', i)
+            blk = None
+        elif blk is not None:
+            t = raw.split(';')[0]
+            if t.strip():
+                blk.append(t)
     # the guarded waits: asm blocks that start with s_waitcnt vmcnt(N) and then move the prefetch registers out
     waits = [i for i, l in enumerate(L) if re.search(r's_waitcnt vmcnt\(\d+\)', l) and first in L[i + 1]]
-    assert len(waits) == 2, (name, waits)
+    require(len(waits) == 2, name, waits)
     counts = sorted(int(re.search(r'vmcnt\((\d+)\)', L[w]).group(1)) for w in waits)
-    assert counts[0] == 0 and counts[1] in strip_counts, (name, counts)
+    require(counts[0] == 0 and counts[1] in strip_counts, name, counts)
     n_expect = counts[1]
     w0 = min(waits)
     # the macroblock loop: the nearest label above the waits that a later instruction branches back to
@@ -68,28 +102,28 @@ def check(L, name):
         if back:
             labi = i
             break
-    assert labi is not None, name
+    require(labi is not None, name)
     # (a) while the loads are in flight -- from the load block of the loop to the back edge, and from the loop head to
     #     the waits -- the compiler must not use v100-v123 (it may use them as scratch registers between a wait and
     #     the next load block: the record has been moved out, the loads are not issued yet)
     loop_loads = [i for i in asm_loads if i > max(waits)]
-    assert len(loop_loads) == n_block, (name, loop_loads)
+    require(len(loop_loads) == n_block, name, loop_loads)
     bad = [(i, l) for i, l in touched if loop_loads[0] <= i <= max(back) or labi <= i <= max(waits)]
-    assert not bad, (name, 'compiler code touches the prefetch registers while loads are in flight', bad[:5])
+    require(not bad, name, 'compiler code touches the prefetch registers while loads are in flight', bad[:5])
     pro = [i for i in asm_loads if i < labi]
     bad = [(i, l) for i, l in touched if pro and pro[0] <= i < labi]
-    assert not bad, (name, 'compiler code touches the prefetch registers behind the prologue loads', bad[:5])
+    require(not bad, name, 'compiler code touches the prefetch registers behind the prologue loads', bad[:5])
     spills = [i for i in range(labi, max(back) + 1) if re.match(r'\s+scratch_', L[i])]
-    assert not spills, (name, 'scratch access inside the macroblock loop', spills[:3])
+    require(not spills, name, 'scratch access inside the macroblock loop', spills[:3])
     in_loop = [i for i in asm_stores_at if labi <= i <= max(back)]
-    assert len(in_loop) == len(asm_stores_at) == n_expect, (name, len(in_loop), len(asm_stores_at), n_expect)
+    require(len(in_loop) == len(asm_stores_at) == n_expect, name, len(in_loop), len(asm_stores_at), n_expect)
     return n_expect, len(asm_loads)
 
 
 def main(path):
     text = open(path).read().split('\n')
     starts = [i for i, l in enumerate(text) if re.match(r'^_ZN4mvhp\d+recon_(quad|oct)_kernel\S+:', l)]
-    assert starts
+    require(starts)
     for s in starts:
         e = next(i for i in range(s, len(text)) if 's_endpgm' in text[i])
         name = text[s].split(':')[0]
