@@ -2,22 +2,20 @@
 // file-backed reader of bitstream.c:382-539 and the Exp-Golomb readers of
 // decoder/h264/h264_expgolomb.c:92-172 for the IDR decode path).
 //
-// A 64-bit window is kept left-aligned in `win_`; reads past the end return
-// zero bits and are detected through the bit position (overrun()).
+// Stateless apart from the bit position: every read is one unaligned big-endian 64-bit load at the current byte,
+// shifted by the bit offset inside it (57 usable bits >= the 32 a read may ask for).  The last 7 bytes of the buffer
+// take a byte-wise path; reads past the end return zero bits and are detected through the position (overrun()).
 #pragma once
 #include <stddef.h>
 #include <stdint.h>
+#include <string.h>
 
 namespace h264 {
 
 class BitReader {
 public:
-    BitReader() : p_(nullptr), n_bytes_(0), n_bits_(0), pos_(0), win_(0), have_(0), next_(0) {}
-    BitReader(const uint8_t *p, size_t n_bytes)
-        : p_(p), n_bytes_(n_bytes), n_bits_(n_bytes * 8), pos_(0), win_(0), have_(0), next_(0)
-    {
-        refill();
-    }
+    BitReader() : p_(nullptr), n_bytes_(0), n_bits_(0), pos_(0) {}
+    BitReader(const uint8_t *p, size_t n_bytes) : p_(p), n_bytes_(n_bytes), n_bits_(n_bytes * 8), pos_(0) {}
 
     size_t pos() const { return pos_; }
     size_t size_bits() const { return n_bits_; }
@@ -27,28 +25,25 @@ public:
     const uint8_t *data() const { return p_; }
 
     // next n bits (n <= 32) without consuming them; zero-padded past the end
-    uint32_t peek(int n)
-    {
-        if (have_ < n) refill();
-        return n ? (uint32_t)(win_ >> (64 - n)) : 0u;
-    }
-    void skip(size_t n)
-    {
-        pos_ += n;
-        if ((size_t)have_ >= n) { win_ <<= n; have_ -= (int)n; }
-        else reseek();
-    }
+    uint32_t peek(int n) const { return n ? (uint32_t)(window() >> (64 - n)) : 0u; }
+    void skip(size_t n) { pos_ += n; }
     uint32_t bits(int n) // n <= 32
     {
         const uint32_t v = peek(n);
-        skip((size_t)n);
+        pos_ += (size_t)n;
         return v;
     }
-    uint32_t bit() { return bits(1); }
-    void seek(size_t bitpos) { pos_ = bitpos; reseek(); }
+    uint32_t bit()
+    {
+        const size_t byte = pos_ >> 3;
+        const uint32_t v = byte < n_bytes_ ? (uint32_t)(p_[byte] >> (7 - (pos_ & 7))) & 1u : 0u;
+        pos_++;
+        return v;
+    }
+    void seek(size_t bitpos) { pos_ = bitpos; }
 
     // number of leading zero bits in the next 32 bits (32 if they are all zero)
-    int leading_zeros32()
+    int leading_zeros32() const
     {
         const uint32_t v = peek(32);
         return v ? __builtin_clz(v) : 32;
@@ -87,32 +82,24 @@ public:
     }
 
 private:
-    void refill()
+    // the bits from the current position on, left-aligned (at least 57 of them valid)
+    uint64_t window() const
     {
-        while (have_ <= 56) {
-            const uint64_t byte = next_ < n_bytes_ ? p_[next_] : 0;
-            next_++;
-            win_ |= byte << (56 - have_);
-            have_ += 8;
+        const size_t byte = pos_ >> 3;
+        uint64_t w;
+        if (byte + 8 <= n_bytes_) {
+            memcpy(&w, p_ + byte, 8);
+            w = __builtin_bswap64(w);
+        } else {
+            w = 0;
+            for (size_t i = byte; i < n_bytes_; i++) w |= (uint64_t)p_[i] << (56 - 8 * (i - byte));
         }
-    }
-    void reseek()
-    {
-        win_ = 0;
-        have_ = 0;
-        next_ = pos_ >> 3;
-        refill();
-        const int off = (int)(pos_ & 7);
-        win_ <<= off;
-        have_ -= off;
+        return w << (pos_ & 7);
     }
 
     const uint8_t *p_;
     size_t n_bytes_, n_bits_;
     size_t pos_;
-    uint64_t win_;
-    int have_;
-    size_t next_;
 };
 
 } // namespace h264

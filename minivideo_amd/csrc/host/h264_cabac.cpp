@@ -12,60 +12,47 @@ namespace h264 {
 
 static inline int clip3(int lo, int hi, int v) { return v < lo ? lo : (v > hi ? hi : v); }
 
+uint8_t CabacEngine::kNextMps[128], CabacEngine::kNextLps[128], CabacEngine::kRangeLpsQ[64][4];
+
+void CabacEngine::build_tables()
+{
+    for (int st = 0; st < 64; st++) {
+        for (int mps = 0; mps < 2; mps++) {
+            kNextMps[st * 2 + mps] = (uint8_t)(kTransMps[st] * 2 + mps);
+            kNextLps[st * 2 + mps] = (uint8_t)(kTransLps[st] * 2 + (st == 0 ? 1 - mps : mps));   // valMPS flips at state 0
+        }
+        for (int q = 0; q < 4; q++) kRangeLpsQ[st][q] = kRangeLps[q][st];
+    }
+}
+
+void CabacEngine::build_tables_once()
+{
+    static const bool done = (build_tables(), true);
+    (void)done;
+}
+
 // initCabacContextVariables (:529) + initCabacDecodingEngine (:581); 9.3.1.1 / 9.3.1.2
 void CabacEngine::init(int slice_qp)
 {
+    build_tables_once();
     const int qp = clip3(0, 51, slice_qp);
     for (int i = 0; i < 460; i++) {
         const int pre = clip3(1, 126, ((kCtxInitM[i] * qp) >> 4) + kCtxInitN[i]);
-        if (pre <= 63) { state_[i] = (uint8_t)(63 - pre); mps_[i] = 0; }
-        else { state_[i] = (uint8_t)(pre - 64); mps_[i] = 1; }
+        if (pre <= 63) st_[i] = (uint8_t)((63 - pre) * 2);
+        else st_[i] = (uint8_t)((pre - 64) * 2 + 1);
     }
     range_ = 510;
-    offset_ = pd_.br_.bits(9);
+    val_ = pd_.br_.bits(9);
+    k_ = 0;
+    refill();
 }
 
-int CabacEngine::decode_decision(int ctx)
-{
-    const uint32_t q = (range_ >> 6) & 3;
-    const uint32_t lps = kRangeLps[q][state_[ctx]];
-    int bin;
-    range_ -= lps;
-    if (offset_ >= range_) {
-        bin = !mps_[ctx];
-        offset_ -= range_;
-        range_ = lps;
-        if (state_[ctx] == 0) mps_[ctx] = 1 - mps_[ctx];
-        state_[ctx] = kTransLps[state_[ctx]];
-    } else {
-        bin = mps_[ctx];
-        state_[ctx] = kTransMps[state_[ctx]];
-    }
-    if (range_ < 256) { // RenormD, :2471 -- all doublings at once
-        const int sh = __builtin_clz(range_) - 23;
-        range_ <<= sh;
-        offset_ = (offset_ << sh) | pd_.br_.bits(sh);
-    }
-    return bin;
-}
+bool CabacEngine::overrun() const { return pd_.br_.pos() > pd_.br_.size_bits() + (size_t)k_; }
 
-int CabacEngine::decode_bypass()
+void CabacEngine::refill()
 {
-    offset_ = (offset_ << 1) | pd_.br_.bit();
-    if (offset_ >= range_) { offset_ -= range_; return 1; }
-    return 0;
-}
-
-int CabacEngine::decode_terminate()
-{
-    range_ -= 2;
-    if (offset_ >= range_) return 1;
-    if (range_ < 256) {
-        const int sh = __builtin_clz(range_) - 23;
-        range_ <<= sh;
-        offset_ = (offset_ << sh) | pd_.br_.bits(sh);
-    }
-    return 0;
+    val_ = (val_ << 32) | pd_.br_.bits(32);
+    k_ += 32;
 }
 
 // mb_type, I slices: binarization Table 9-36, ctxIdxOffset 3; ctxIdxInc 9.3.3.1.1.3 (:1548-1596)
@@ -202,7 +189,7 @@ int CabacEngine::cbf_ctx_inc(int addr, int cat, int blkIdx) const
 }
 
 // residual_block_cabac, :138-325; ctxIdx assignment 9.3.3.1.3 / Table 9-40 (:2266-2340)
-int CabacEngine::residual_block(int addr, int *coeffLevel, int startIdx, int endIdx, int maxNumCoeff, int cat, int blkIdx)
+int CabacEngine::residual_block(int addr, int startIdx, int endIdx, int maxNumCoeff, int cat, int blkIdx)
 {
     static const int kCbfOff[8] = {0, 8, 0, 4, 12, 12, 16, 16};
     static const int kSigOff[8] = {0, 29, 0, 15, 44, 44, 47, 47};
@@ -269,7 +256,7 @@ int CabacEngine::residual_block(int addr, int *coeffLevel, int startIdx, int end
         const int lvl = v + 1;
         if (lvl == 1) eq1++; else gt1++;
         if (i >= 64) return RC_FAILURE;
-        coeffLevel[i] = sign ? -lvl : lvl;
+        pd_.put(i, sign ? -lvl : lvl);
     }
     (void)maxNumCoeff;
     return RC_SUCCESS;

@@ -27,9 +27,53 @@ class PictureDecoder;
 struct CabacEngine {
     explicit CabacEngine(PictureDecoder &pd) : pd_(pd) {}
     void init(int slice_qp);                          // :529-615
-    int  decode_decision(int ctxIdx);                 // :2380-2469
-    int  decode_bypass();                             // :2506
-    int  decode_terminate();                          // :2542
+    bool overrun() const;                             // the standard's 9-bit register would have read past the end
+    // The arithmetic decoder of 9.3.3.2 (DecodeDecision :2380-2469, RenormD :2471, DecodeBypass :2506,
+    // DecodeTerminate :2542) with codIOffset kept `k_` bits ahead of the standard's 9-bit register: val_ =
+    // codIOffset << k_ | the next k_ bits of the slice data, so a comparison against codIRange << k_ is the standard's
+    // comparison, renormalisation only lowers k_, and the bit reader is asked for 32 bits at a time.
+    int decode_decision(int ctx)
+    {
+        const uint32_t st = st_[ctx];
+        const uint32_t lps = kRangeLpsQ[st >> 1][(range_ >> 6) & 3];
+        range_ -= lps;
+        const uint64_t scaled = (uint64_t)range_ << k_;
+        int bin = (int)(st & 1u);
+        if (val_ >= scaled) {
+            val_ -= scaled;
+            range_ = lps;
+            bin ^= 1;
+            st_[ctx] = kNextLps[st];
+        } else {
+            st_[ctx] = kNextMps[st];
+        }
+        if (range_ < 256) {
+            const int sh = __builtin_clz(range_) - 23;
+            range_ <<= sh;
+            k_ -= sh;
+            if (k_ < 16) refill();
+        }
+        return bin;
+    }
+    int decode_bypass()
+    {
+        if (--k_ < 16) refill();
+        const uint64_t scaled = (uint64_t)range_ << k_;
+        if (val_ >= scaled) { val_ -= scaled; return 1; }
+        return 0;
+    }
+    int decode_terminate()
+    {
+        range_ -= 2;
+        if (val_ >= ((uint64_t)range_ << k_)) return 1;
+        if (range_ < 256) {
+            const int sh = __builtin_clz(range_) - 23;
+            range_ <<= sh;
+            k_ -= sh;
+            if (k_ < 16) refill();
+        }
+        return 0;
+    }
 
     unsigned mb_type(int addr);
     int      transform_size_8x8_flag(int addr);
@@ -38,14 +82,21 @@ struct CabacEngine {
     unsigned intra_chroma_pred_mode(int addr);
     unsigned coded_block_pattern(int addr);
     int      mb_qp_delta(int addr);
-    int      residual_block(int addr, int *coeff, int startIdx, int endIdx, int maxNumCoeff, int cat, int blkIdx);
+    int      residual_block(int addr, int startIdx, int endIdx, int maxNumCoeff, int cat, int blkIdx);
 
 private:
     int  cbf_ctx_inc(int addr, int cat, int blkIdx) const;
+    void refill();
     PictureDecoder &pd_;
-    uint8_t  state_[460];
-    uint8_t  mps_[460];
-    uint32_t range_ = 510, offset_ = 0;
+    uint8_t  st_[460];            // pStateIdx << 1 | valMPS
+    uint32_t range_ = 510;
+    uint64_t val_ = 0;
+    int      k_ = 0;
+    // transitions on the combined state byte, rangeTabLPS as [state][quarter]: built once from Tables 9-44 / 9-45
+    static uint8_t kNextMps[128], kNextLps[128], kRangeLpsQ[64][4];
+    static void build_tables();
+public:
+    static void build_tables_once();
 };
 
 } // namespace h264

@@ -57,15 +57,26 @@ int index_annexb(const uint8_t *data, size_t size, std::vector<EsSample> &out)
 // H4: emulation prevention removal (h264_nalu.c:195-249)
 void unescape_rbsp(const uint8_t *src, size_t n, std::vector<uint8_t> &dst)
 {
-    dst.clear();
-    dst.reserve(n);
-    int zeros = 0;
-    for (size_t i = 0; i < n; i++) {
-        const uint8_t b = src[i];
-        if (zeros >= 2 && b == 0x03) { zeros = 0; continue; }
-        dst.push_back(b);
-        zeros = (b == 0) ? zeros + 1 : 0;
+    // an emulation prevention byte is a 0x03 behind two zero bytes of the input (a removed byte resets the zero run,
+    // and it is not zero itself, so looking back two input bytes is the same test as counting zeros while copying);
+    // everything between two of them is copied in one piece
+    dst.resize(n);
+    uint8_t *d = dst.data();
+    size_t from = 0, o = 0, i = 0;
+    while (i < n) {
+        const uint8_t *hit = static_cast<const uint8_t *>(memchr(src + i, 0x03, n - i));
+        if (!hit) break;
+        i = (size_t)(hit - src);
+        if (i >= 2 && src[i - 1] == 0 && src[i - 2] == 0) {
+            memcpy(d + o, src + from, i - from);
+            o += i - from;
+            from = i + 1;
+        }
+        i++;
     }
+    memcpy(d + o, src + from, n - from);
+    o += n - from;
+    dst.resize(o);
 }
 
 // ---------------------------------------------------------------------------
@@ -189,14 +200,16 @@ int PictureDecoder::decode(const uint8_t *rbsp, size_t n, uint8_t *packed, size_
 {
     if ((size_t)W_ * H_ * MVHP_MB_BYTES != packed_bytes) { err = "packed buffer size mismatch"; return RC_FAILURE; }
     br_ = BitReader(rbsp, n);
-    out_ = packed;
-    memset(out_, 0, packed_bytes);
+    out_ = packed;   // (every record is zeroed right before its macroblock is parsed: macroblock())
     mbs_.assign((size_t)W_ * H_, MbState());
     level_overflow_ = false;
     int rc = slice_header(err);
     if (rc != RC_SUCCESS) return rc;
     rc = slice_data(err);
-    if (rc != RC_SUCCESS) return rc;
+    if (rc != RC_SUCCESS) {   // the records behind the failure were never written: leave no stale bytes in the buffer
+        memset(out_, 0, packed_bytes);
+        return rc;
+    }
     if (level_overflow_) { err = "transform coefficient level outside int16"; return RC_FAILURE; }
     return RC_SUCCESS;
 }
@@ -258,7 +271,7 @@ int PictureDecoder::slice_data(std::string &err)
                 break;
             }
         }
-        if (br_.overrun()) { err = "slice data truncated"; return RC_FAILURE; }
+        if (pps_.entropy_coding_mode ? cabac_->overrun() : br_.overrun()) { err = "slice data truncated"; return RC_FAILURE; }
     }
     return RC_SUCCESS;
 }
@@ -337,6 +350,7 @@ int PictureDecoder::macroblock(int addr, std::string &err)
 {
     MbState &mb = mbs_[addr];
     const bool cabac = pps_.entropy_coding_mode;
+    memset(out_ + (size_t)addr * MVHP_MB_BYTES, 0, MVHP_MB_BYTES);   // levels are written sparsely into a zero record
     const unsigned mb_type = cabac ? cabac_->mb_type(addr) : br_.ue();
     if (mb_type == 25) { err = "I_PCM macroblocks are not supported"; return RC_UNSUPPORTED; } // :151-154
     if (mb_type > 25) { err = "invalid mb_type in an I slice"; return RC_FAILURE; }
@@ -385,6 +399,7 @@ int PictureDecoder::macroblock(int addr, std::string &err)
         mb.cbp_chroma = (uint8_t)(cbp / 16);
     }
     int mb_qp_delta = 0;
+    nz_cur_ = 0;
     if (mb.cbp_luma > 0 || mb.cbp_chroma > 0 || mb.kind == MVHP_KIND_I16x16) {
         mb_qp_delta = cabac ? cabac_->mb_qp_delta(addr) : br_.se();
         mb.qp_delta_nonzero = mb_qp_delta != 0;
@@ -407,12 +422,7 @@ int PictureDecoder::macroblock(int addr, std::string &err)
     h.i16_pred_mode = (uint8_t)i16_mode;
     memcpy(h.pred_mode, mb.pred, 16);
     uint8_t *rec = out_ + (size_t)addr * MVHP_MB_BYTES;
-    uint32_t nz = 0;
-    for (int b = 0; b < 24; b++) { // 16 levels = four 64-bit words per block
-        uint64_t w[4];
-        memcpy(w, rec + MVHP_MB_HEADER_BYTES + b * 32, 32);
-        if (w[0] | w[1] | w[2] | w[3]) nz |= 1u << b;
-    }
+    uint32_t nz = nz_cur_;   // collected while the blocks were decoded: every decoded level is non-zero
     if (mb.kind == MVHP_KIND_I8x8)
         for (int k = 0; k < 4; k++)
             if (nz & (0xfu << (4 * k))) nz |= 0xfu << (4 * k);
@@ -421,39 +431,59 @@ int PictureDecoder::macroblock(int addr, std::string &err)
     return RC_SUCCESS;
 }
 
-// inverse scan + placement of one decoded block into the packed record
-void PictureDecoder::scatter(int addr, int cat, int blkIdx, const int *coeff, int n)
+// Where a decoded level goes: entropy decoders hand (coefficient index, level) pairs to put(), which applies the
+// inverse scan (h264_transform.c:440-480, a pure permutation) and the record layout of include/minivideo_hotpath.h in
+// one table lookup, and notes which blocks hold a level (nz_mask).
+namespace {
+struct SinkTables {
+    uint8_t l4[16];        // 4x4 block, coefficient i -> raster slot
+    uint8_t ac[16];        // Intra16x16 / chroma AC: coefficient k is zig-zag position k + 1
+    uint8_t dc16[16];      // Intra16x16 DC: coefficient i -> slot 0 of the block at that raster position (/16)
+    uint8_t l8[64];        // 8x8 block
+    uint8_t l8i[4][16];    // CAVLC 8x8: four interleaved 4x4 blocks, coefficient i of part p = 8x8 index 4i + p
+    SinkTables()
+    {
+        for (int i = 0; i < 16; i++) {
+            l4[i] = kZigzag4x4[i];
+            ac[i] = kZigzag4x4[i < 15 ? i + 1 : 15];
+            const int rc = kZigzag4x4[i];
+            dc16[i] = (uint8_t)blk4_from_xy((rc & 3) * 4, (rc >> 2) * 4);
+        }
+        for (int i = 0; i < 64; i++) l8[i] = kZigzag8x8[i];
+        for (int p = 0; p < 4; p++)
+            for (int i = 0; i < 16; i++) l8i[p][i] = kZigzag8x8[4 * i + p];   // h264_macroblock.c:1175-1184
+    }
+};
+const SinkTables g_sink;
+} // namespace
+
+void PictureDecoder::sink_begin(int addr, int cat, int blkIdx, int part)
 {
     int16_t *coef = reinterpret_cast<int16_t *>(out_ + (size_t)addr * MVHP_MB_BYTES + MVHP_MB_HEADER_BYTES);
-    auto put = [&](int idx, int v) {
-        if (v > 32767 || v < -32768) { level_overflow_ = true; v = 0; }
-        coef[idx] = (int16_t)v;
-    };
+    sink_.scale = 1;
+    sink_.nz_per_coef = false;
     switch (cat) {
-    case CAT_LUMA_8x8: // coeff[64] in 8x8 zig-zag order
-        for (int i = 0; i < n; i++) if (coeff[i]) put(blkIdx * 64 + kZigzag8x8[i], coeff[i]);
+    case CAT_LUMA_8x8:
+        if (part >= 0) { sink_.tab = g_sink.l8i[part]; }
+        else sink_.tab = g_sink.l8;
+        sink_.dst = coef + blkIdx * 64;
+        sink_.nz_bit = 0xfu << (4 * blkIdx);
         break;
-    case CAT_LUMA_4x4:
-        for (int i = 0; i < n; i++) if (coeff[i]) put(blkIdx * 16 + kZigzag4x4[i], coeff[i]);
+    case CAT_LUMA_4x4: sink_.tab = g_sink.l4; sink_.dst = coef + blkIdx * 16; sink_.nz_bit = 1u << blkIdx; break;
+    case CAT_LUMA_16x16_DC:   // c1[row][col] -> slot 0 of the block at that raster position
+        sink_.tab = g_sink.dc16; sink_.dst = coef; sink_.scale = 16; sink_.nz_bit = 1u; sink_.nz_per_coef = true;
         break;
-    case CAT_LUMA_16x16_DC: // c1[row][col] -> slot 0 of the block at that raster position
-        for (int i = 0; i < n; i++)
-            if (coeff[i]) {
-                const int rc = kZigzag4x4[i];
-                put(blk4_from_xy((rc & 3) * 4, (rc >> 2) * 4) * 16, coeff[i]);
-            }
-        break;
-    case CAT_LUMA_16x16_AC: // coeff[k] is zig-zag position k+1
-        for (int i = 0; i < n; i++) if (coeff[i]) put(blkIdx * 16 + kZigzag4x4[i + 1], coeff[i]);
-        break;
+    case CAT_LUMA_16x16_AC: sink_.tab = g_sink.ac; sink_.dst = coef + blkIdx * 16; sink_.nz_bit = 1u << blkIdx; break;
     case CAT_CHROMA_DC_CB:
-    case CAT_CHROMA_DC_CR:
-        for (int i = 0; i < n; i++) if (coeff[i]) put(256 + (cat - CAT_CHROMA_DC_CB) * 64 + i * 16, coeff[i]);
+    case CAT_CHROMA_DC_CR: {   // DC level k -> slot 0 of chroma block k
+        static const uint8_t ident[4] = {0, 1, 2, 3};
+        sink_.tab = ident; sink_.dst = coef + 256 + (cat - CAT_CHROMA_DC_CB) * 64; sink_.scale = 16;
+        sink_.nz_bit = 1u << (16 + 4 * (cat - CAT_CHROMA_DC_CB)); sink_.nz_per_coef = true;
         break;
-    case CAT_CHROMA_AC_CB:
-    case CAT_CHROMA_AC_CR:
-        for (int i = 0; i < n; i++)
-            if (coeff[i]) put(256 + (cat - CAT_CHROMA_AC_CB) * 64 + blkIdx * 16 + kZigzag4x4[i + 1], coeff[i]);
+    }
+    default:   // chroma AC
+        sink_.tab = g_sink.ac; sink_.dst = coef + 256 + (cat - CAT_CHROMA_AC_CB) * 64 + blkIdx * 16;
+        sink_.nz_bit = 1u << (16 + 4 * (cat - CAT_CHROMA_AC_CB) + blkIdx);
         break;
     }
 }
@@ -463,57 +493,45 @@ int PictureDecoder::residual(int addr, std::string &err)
 {
     MbState &mb = mbs_[addr];
     const bool cabac = pps_.entropy_coding_mode;
-    int coeff[64];
-    auto block = [&](int cat, int blkIdx, int startIdx, int endIdx, int maxNum) -> int {
-        memset(coeff, 0, sizeof(coeff));
-        int rc = cabac ? cabac_->residual_block(addr, coeff, startIdx, endIdx, maxNum, cat, blkIdx)
-                       : residual_block_cavlc(addr, coeff, startIdx, endIdx, maxNum, cat, blkIdx);
-        if (rc != RC_SUCCESS) return rc;
-        return RC_SUCCESS;
+    auto block = [&](int cat, int blkIdx, int part, int endIdx, int maxNum) -> int {
+        sink_begin(addr, cat, blkIdx, part);
+        const int cat_e = (part >= 0) ? CAT_LUMA_4x4 : cat;   // a CAVLC 8x8 block is parsed as four 4x4 blocks
+        const int blk_e = (part >= 0) ? blkIdx * 4 + part : blkIdx;
+        return cabac ? cabac_->residual_block(addr, 0, endIdx, maxNum, cat_e, blk_e)
+                     : residual_block_cavlc(addr, 0, endIdx, maxNum, cat_e, blk_e);
     };
     if (mb.kind == MVHP_KIND_I16x16) {
-        if (block(CAT_LUMA_16x16_DC, 0, 0, 15, 16) != RC_SUCCESS) { err = "residual: Intra16x16 DC block"; return RC_FAILURE; }
-        scatter(addr, CAT_LUMA_16x16_DC, 0, coeff, 16);
+        if (block(CAT_LUMA_16x16_DC, 0, -1, 15, 16) != RC_SUCCESS) { err = "residual: Intra16x16 DC block"; return RC_FAILURE; }
     }
     for (int i8 = 0; i8 < 4; i8++) {
         if (!mb.transform8x8 || !cabac) {
-            int c8[64];
-            memset(c8, 0, sizeof(c8));
             for (int i4 = 0; i4 < 4; i4++) {
                 const int blk = i8 * 4 + i4;
                 if (mb.cbp_luma & (1 << i8)) {
                     if (mb.kind == MVHP_KIND_I16x16) {
-                        if (block(CAT_LUMA_16x16_AC, blk, 0, 14, 15) != RC_SUCCESS) { err = "residual: Intra16x16 AC block"; return RC_FAILURE; }
-                        scatter(addr, CAT_LUMA_16x16_AC, blk, coeff, 15);
+                        if (block(CAT_LUMA_16x16_AC, blk, -1, 14, 15) != RC_SUCCESS) { err = "residual: Intra16x16 AC block"; return RC_FAILURE; }
+                    } else if (mb.transform8x8) {   // :1175-1184: coefficient i of 4x4 block i4 is 8x8 coefficient 4i + i4
+                        if (block(CAT_LUMA_8x8, i8, i4, 15, 16) != RC_SUCCESS) { err = "residual: luma 4x4 block"; return RC_FAILURE; }
                     } else {
-                        if (block(CAT_LUMA_4x4, blk, 0, 15, 16) != RC_SUCCESS) { err = "residual: luma 4x4 block"; return RC_FAILURE; }
-                        if (mb.transform8x8) {
-                            for (int i = 0; i < 16; i++) c8[4 * i + i4] = coeff[i]; // :1175-1184
-                        } else {
-                            scatter(addr, CAT_LUMA_4x4, blk, coeff, 16);
-                        }
+                        if (block(CAT_LUMA_4x4, blk, -1, 15, 16) != RC_SUCCESS) { err = "residual: luma 4x4 block"; return RC_FAILURE; }
                     }
                 } else {
                     mb.tc_luma[blk] = 0;
                 }
             }
-            if (mb.transform8x8 && (mb.cbp_luma & (1 << i8))) scatter(addr, CAT_LUMA_8x8, i8, c8, 64);
         } else if (mb.cbp_luma & (1 << i8)) {
-            if (block(CAT_LUMA_8x8, i8, 0, 63, 64) != RC_SUCCESS) { err = "residual: luma 8x8 block"; return RC_FAILURE; }
-            scatter(addr, CAT_LUMA_8x8, i8, coeff, 64);
+            if (block(CAT_LUMA_8x8, i8, -1, 63, 64) != RC_SUCCESS) { err = "residual: luma 8x8 block"; return RC_FAILURE; }
         }
     }
     for (int c = 0; c < 2; c++) {
         if (mb.cbp_chroma & 3) {
-            if (block(CAT_CHROMA_DC_CB + c, 0, 0, 3, 4) != RC_SUCCESS) { err = "residual: chroma DC block"; return RC_FAILURE; }
-            scatter(addr, CAT_CHROMA_DC_CB + c, 0, coeff, 4);
+            if (block(CAT_CHROMA_DC_CB + c, 0, -1, 3, 4) != RC_SUCCESS) { err = "residual: chroma DC block"; return RC_FAILURE; }
         }
     }
     for (int c = 0; c < 2; c++) {
         for (int blk = 0; blk < 4; blk++) {
             if (mb.cbp_chroma & 2) {
-                if (block(CAT_CHROMA_AC_CB + c, blk, 0, 14, 15) != RC_SUCCESS) { err = "residual: chroma AC block"; return RC_FAILURE; }
-                scatter(addr, CAT_CHROMA_AC_CB + c, blk, coeff, 15);
+                if (block(CAT_CHROMA_AC_CB + c, blk, -1, 14, 15) != RC_SUCCESS) { err = "residual: chroma AC block"; return RC_FAILURE; }
             }
         }
     }
@@ -551,6 +569,7 @@ int PictureDecoder::nC_for(int addr, int cat, int blkIdx) const
 struct CavlcTables {
     uint32_t coeff_token[3][17][8];
     uint16_t total_zeros[15][512];   // index: next 9 bits -> len | value << 8
+    uint16_t coeff_token_cdc[256];   // chroma DC (nC = -1): next 8 bits -> len | total << 4 | trailing_ones << 8
     uint8_t  total_zeros_cdc[3][8];  // next 3 bits -> len | value << 4
     uint8_t  run_before[6][8];       // zerosLeft 1..6: next 3 bits -> len | value << 4
     CavlcTables()
@@ -568,6 +587,13 @@ struct CavlcTables {
                     for (int fill = 0; fill < (1 << (3 - sfx)); fill++)
                         coeff_token[tab][lz][(sfx_bits << (3 - sfx)) | fill] = (uint32_t)len | (n << 8) | (t << 16);
                 }
+        for (int t = 0; t < 4; t++)
+            for (int n = 0; n < 5; n++) {
+                const int len = kCoeffTokenChromaDcLen[t][n], code = kCoeffTokenChromaDcCode[t][n];
+                if (!len) continue;
+                for (int fill = 0; fill < (1 << (8 - len)); fill++)
+                    coeff_token_cdc[(code << (8 - len)) | fill] = (uint16_t)(len | (n << 4) | (t << 8));
+            }
         for (int v = 0; v < 15; v++)
             for (int z = 0; z < 16; z++) {
                 const int len = kTotalZerosLen[v][z], code = kTotalZerosCode[v][z];
@@ -593,8 +619,7 @@ struct CavlcTables {
 };
 static const CavlcTables g_cavlc;
 
-int PictureDecoder::residual_block_cavlc(int addr, int *coeffLevel, int startIdx, int endIdx, int maxNumCoeff, int cat,
-                                         int blkIdx)
+int PictureDecoder::residual_block_cavlc(int addr, int startIdx, int endIdx, int maxNumCoeff, int cat, int blkIdx)
 {
     MbState &mb = mbs_[addr];
     const int nC = nC_for(addr, cat, blkIdx);
@@ -605,11 +630,8 @@ int PictureDecoder::residual_block_cavlc(int addr, int *coeffLevel, int startIdx
         if (v == 3) { total = 0; t1s = 0; }
         else { total = (int)(v >> 2) + 1; t1s = (int)(v & 3); if (t1s > total) return RC_FAILURE; }
     } else if (nC == -1) {
-        for (int t = 0; t < 4 && total < 0; t++)
-            for (int n = 0; n < 5; n++) {
-                const int l = kCoeffTokenChromaDcLen[t][n];
-                if (l && br_.peek(l) == kCoeffTokenChromaDcCode[t][n]) { br_.skip(l); total = n; t1s = t; break; }
-            }
+        const uint16_t e = g_cavlc.coeff_token_cdc[br_.peek(8)];
+        if (e) { br_.skip(e & 15u); total = (e >> 4) & 15; t1s = e >> 8; }
     } else {
         const int tab = nC < 2 ? 0 : (nC < 4 ? 1 : 2);
         const int lz = br_.leading_zeros32();
@@ -697,7 +719,7 @@ int PictureDecoder::residual_block_cavlc(int addr, int *coeffLevel, int startIdx
     for (int i = total - 1; i >= 0; i--) {
         coeffNum += run[i] + 1;
         if (startIdx + coeffNum > endIdx || startIdx + coeffNum >= 64) return RC_FAILURE;
-        coeffLevel[startIdx + coeffNum] = level[i];
+        put(startIdx + coeffNum, level[i]);
     }
     return RC_SUCCESS;
 }

@@ -106,9 +106,24 @@ private:
     int  macroblock(int addr, std::string &err);
     void derive_pred_modes(int addr, const uint8_t prev_flag[16], const uint8_t rem[16]);
     int  residual(int addr, std::string &err);
-    int  residual_block_cavlc(int addr, int *coeff, int startIdx, int endIdx, int maxNumCoeff, int cat, int blkIdx);
+    int  residual_block_cavlc(int addr, int startIdx, int endIdx, int maxNumCoeff, int cat, int blkIdx);
     int  nC_for(int addr, int cat, int blkIdx) const;
-    void scatter(int addr, int cat, int blkIdx, const int *coeff, int n);
+    // destination of the block being decoded: coefficient index -> int16 slot of the packed record
+    struct Sink {
+        int16_t       *dst = nullptr;
+        const uint8_t *tab = nullptr;
+        int            scale = 1;
+        uint32_t       nz_bit = 0;
+        bool           nz_per_coef = false;   // DC blocks: level i marks block tab[i] (its slot 0 holds the level)
+    };
+    void sink_begin(int addr, int cat, int blkIdx, int part);
+    void put(int idx, int v)
+    {
+        if (v > 32767 || v < -32768) { level_overflow_ = true; v = 0; }
+        const int slot = sink_.tab[idx];
+        sink_.dst[slot * sink_.scale] = (int16_t)v;
+        nz_cur_ |= sink_.nz_per_coef ? (sink_.nz_bit << slot) : sink_.nz_bit;
+    }
 
     // neighbour helpers: address of MB A/B or -1
     int mbA(int addr) const { return (addr % W_) > 0 ? addr - 1 : -1; }
@@ -124,6 +139,8 @@ private:
     int        slice_qp_ = 26, qp_prev_ = 26;
     CabacEngine *cabac_ = nullptr;
     bool       level_overflow_ = false;
+    Sink       sink_;
+    uint32_t   nz_cur_ = 0;      // nz_mask of the macroblock being decoded
 };
 
 } // namespace h264
