@@ -98,6 +98,11 @@ typedef struct mvhp_stream_params {
 /* flags: the batch may contain Intra8x8 macroblocks (PPS transform_8x8_mode_flag).  A hint for the kernel choice
  * only -- every kernel reconstructs every macroblock kind; callers that build records themselves may leave it 0. */
 #define MVHP_PARAM_MAY_HAVE_8X8 1u
+/* flags: Intra16x16 luma DC dequantisation by the standard's rule (qP >= 36 takes the left-shift branch, 8.5.10) instead
+ * of the reference's `qP > 36` (h264_transform.c:797-808), i.e. without the reference's QP'Y = 36 defect.  Results
+ * differ from the reference exactly on Intra16x16 macroblocks at QP'Y = 36.  Set by streams opened with
+ * MVHP_STREAM_SPEC (outside the parity contract, opt-in). */
+#define MVHP_PARAM_SPEC_LUMA_DC 2u
 
 /* Bytes of one reconstructed picture: planar Y | Cb | Cr of the *uncropped*
  * coded size (export.c:80-81), and interleaved RGB8. */
@@ -113,6 +118,13 @@ typedef struct mvhp_stream mvhp_stream_t;   /* parsed elementary stream */
 /* Index + parse parameter sets of an Annex-B buffer held in memory.
  * The buffer must outlive the handle. */
 MVHP_EXPORT int  mvhp_stream_open(const uint8_t *data, size_t size, mvhp_stream_t **out);
+/* The same with flags.  0 = reference parity (everything above).  MVHP_STREAM_SPEC (opt-in; also
+ * chosen by minivideo_decode when the environment has MINIVIDEO_SPEC=1): index the stream the way the standard
+ * defines it instead of the way esparser.c:40-143 does -- three-byte start codes (Annex B), slice / SPS / PPS NAL units
+ * of any nal_ref_idc, no 32-byte blind tail -- and reconstruct Intra16x16 at QP'Y = 36 by the standard's rule
+ * (MVHP_PARAM_SPEC_LUMA_DC).  Still one slice per picture: a picture of several slices is refused. */
+#define MVHP_STREAM_SPEC 1u
+MVHP_EXPORT int  mvhp_stream_open_ex(const uint8_t *data, size_t size, uint32_t flags, mvhp_stream_t **out);
 /* Same for an ISO-BMFF (MP4/MOV) buffer: avcC parameter sets + the IDR NAL units of the sync samples of the first
  * video track (replaces demuxer/mp4/mp4.c:2587 mp4_fileParse for the thumbnail path). */
 MVHP_EXPORT int  mvhp_stream_open_mp4(const uint8_t *data, size_t size, mvhp_stream_t **out);

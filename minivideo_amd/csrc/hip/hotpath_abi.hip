@@ -254,6 +254,7 @@ static int launch_all(mvhp_ctx *c, const mvhp_stream_params_t *p, const void *d_
         a.cqp_off_cb = p->chroma_qp_index_offset;
         a.cqp_off_cr = p->second_chroma_qp_index_offset;
         a.n_frames = n_frames;
+        a.dc_shift_from = (p->flags & MVHP_PARAM_SPEC_LUMA_DC) ? 36 : 37;
         const int layout = pick_layout(c, p, n_frames);
         const int nw = pick_waves(c, p, n_frames, layout);
         c->last_layout = layout;

@@ -14,6 +14,8 @@ struct ReconArgs {
     int            width_mbs, height_mbs;
     int            cqp_off_cb, cqp_off_cr;
     int            n_frames;
+    int            dc_shift_from;   // Intra16x16 luma DC takes the left-shift branch from this qP on: 37 = the reference's
+                                    // `qP > 36` (h264_transform.c:797), 36 = the standard (MVHP_PARAM_SPEC_LUMA_DC)
 };
 
 struct ColorArgs {

@@ -64,6 +64,7 @@ struct __attribute__((aligned(16))) BlockLds {
 struct PairCtl {
     int kind[2], qpy[2], qpc_cb[2], qpc_cr[2];
     bool need[2];
+    int dc_shift_from;   // ReconArgs::dc_shift_from
 };
 
 __device__ __forceinline__ void residual_pair(WaveLds &W, const BlockLds &B, int lane, const int4 cA, const int4 cB,
@@ -157,7 +158,7 @@ __device__ __forceinline__ void residual_pair(WaveLds &W, const BlockLds &B, int
                 const int v = W.scr[24 * sel + q];            // c[ri][rj]
                 f += (hneg(bi, ri) != hneg(rj, bj)) ? -v : v; // H4[bi][ri] * c * H4[rj][bj]
             }
-            if (qpy > 36) dc = (int)((unsigned)(f * lsA) << ((s - 6) & 31));
+            if (qpy >= pc.dc_shift_from) dc = (int)((unsigned)(f * lsA) << ((s - 6) & 31));
             else dc = (int)((unsigned)(f * lsA) + (1u << ((5 - s) & 31))) >> ((6 - s) & 31);
         }
         // quant4x4, h264_transform.c:1100-1134.  qP differs between lanes, so the two cases are merged:
@@ -618,11 +619,12 @@ __global__ __launch_bounds__(NW * 64) void recon_rows_kernel(ReconArgs a)
                 }
                 // Intra16x16 at QP'Y == 36 yields a non-zero DC term even from all-zero levels
                 // (h264_transform.c:797-808), so the residual stage cannot be skipped there.
-                const bool quirk36 = (pc.kind[k] == MVHP_KIND_I16x16) && (pc.qpy[k] == 36);
+                const bool quirk36 = (pc.kind[k] == MVHP_KIND_I16x16) && (pc.qpy[k] == 36) && (a.dc_shift_from > 36);
                 rl[k] = ((hnz[k] & 0xffffu) != 0) || quirk36;
                 rc[k] = (hnz[k] & 0xff0000u) != 0;
                 pc.need[k] = (rl[k] || rc[k]) && (k < npair);
             }
+            pc.dc_shift_from = a.dc_shift_from;
             if (pc.need[0] || pc.need[1]) residual_pair(Wv, B, lane_p, cA, cB, pc);
 
 #pragma unroll 1

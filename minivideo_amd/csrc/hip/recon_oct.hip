@@ -28,6 +28,11 @@ namespace mvhp {
 #ifndef MVHP_LOAD_HINT
 #define MVHP_LOAD_HINT ""   // cache-policy suffix of the record loads (measurement builds try " nt")
 #endif
+#ifdef MVHP_MARKS   // measurement builds: section markers that survive into the ISA text (tools/isa_sections.py)
+#define MVHP_MARK(name) asm volatile("; MARK " name ::: "memory")
+#else
+#define MVHP_MARK(name)
+#endif
 #ifndef MVHP_CHAIN_PRIO
 #define MVHP_CHAIN_PRIO 2   // wave priority inside the Intra4x4 chain (measured: 0 -> 2 = -2 % / -6 % kernel time with / without RGB)
 #endif
@@ -144,6 +149,7 @@ __global__ __launch_bounds__(NW * 64) void recon_oct_kernel(ReconArgs a)
             uint8_t *line_cr = line_cb + W * 8;
             const bool A = mbx > 0, C = Bv && (mbx < W - 1), D = A && Bv;
 
+            MVHP_MARK("prefetch_wait");
             // wait for the prefetched record and move it into compiler-visible registers
             v2i w[16];
 #define MVHP_WAIT_PREFETCH(N)                                                                                          \
@@ -169,6 +175,7 @@ __global__ __launch_bounds__(NW * 64) void recon_oct_kernel(ReconArgs a)
                 if (nrow >= H) { nrow = row; nx = mbx; }
                 prefetch(nrow, nx, lane);
             }
+            MVHP_MARK("header");
             const uint32_t h0 = (uint32_t)w[0].x, h1 = (uint32_t)w[0].y, nz = (uint32_t)w[1].x;
             const uint32_t m0 = (uint32_t)w[1].y, m1 = (uint32_t)w[2].x, m2 = (uint32_t)w[2].y, m3 = (uint32_t)w[3].x;
             const int kind = h0 & 255;
@@ -176,7 +183,7 @@ __global__ __launch_bounds__(NW * 64) void recon_oct_kernel(ReconArgs a)
             const int cmode = (h0 >> 24) & 255, i16mode = h1 & 255;
             // Intra16x16 at QP'Y == 36 yields a non-zero DC term even from all-zero levels
             // (h264_transform.c:797-808), so the residual stage cannot be skipped there.
-            const bool quirk36 = (kind == MVHP_KIND_I16x16) && (qpy == 36);
+            const bool quirk36 = (kind == MVHP_KIND_I16x16) && (qpy == 36) && (a.dc_shift_from > 36);
             const bool need_l = ((nz & 0xffffu) != 0) || quirk36;
             const bool need_c = (nz & 0xff0000u) != 0;
             const bool any_l = __builtin_amdgcn_ballot_w64(need_l) != 0;
@@ -190,6 +197,7 @@ __global__ __launch_bounds__(NW * 64) void recon_oct_kernel(ReconArgs a)
             // =====================================================================================
             // residuals
             // =====================================================================================
+            MVHP_MARK("resid_luma");
             int r2[2][8];   // luma blocks 2j, 2j+1: residuals packed by row pairs (see idct4x4_ypairs)
             int c2[8];      // chroma block j
 #pragma unroll
@@ -201,6 +209,7 @@ __global__ __launch_bounds__(NW * 64) void recon_oct_kernel(ReconArgs a)
                     // ---- luma 8x8 (transform_8x8_residual, h264_transform.c:1205-1383): lane j holds rows
                     //      4*(j&1) .. +3 of 8x8 block j >> 1; rows in registers, columns after an LDS transpose,
                     //      two blocks at a time ----
+MVHP_MARK("r_8x8");
                     const int hh = j & 1;
                     const int *l8 = &B.ls8[m * 6];
                     const int ls0 = l8[0], ls1 = l8[1], ls2 = l8[2], ls3 = l8[3], ls4 = l8[4], ls5 = l8[5];
@@ -253,6 +262,7 @@ __global__ __launch_bounds__(NW * 64) void recon_oct_kernel(ReconArgs a)
                     }
                 } else {
                     // ---- luma 4x4 (transform_4x4_residual, h264_transform.c:1049-1191), two blocks per lane ----
+MVHP_MARK("r_4x4_dc");
                     int dc0 = 0, dc1 = 0;
                     if (kind == MVHP_KIND_I16x16) {
                         // transform_16x16_lumadc, h264_transform.c:756-812 (incl. the `qP > 36` test).  Block 2j+s sits at
@@ -269,7 +279,7 @@ __global__ __launch_bounds__(NW * 64) void recon_oct_kernel(ReconArgs a)
                         const int f0 = had4_lanes(g0, dpp_quad<DPP_XOR1>(g0), ci, aP, aP | (4 << 2));
                         const int f1 = had4_lanes(g1, dpp_quad<DPP_XOR1>(g1), ci, aP, aP | (4 << 2));
                         const int lsA = B.ls0[qpy];
-                        if (qpy > 36) {
+                        if (qpy >= a.dc_shift_from) {
                             dc0 = (int)((unsigned)(f0 * lsA) << ((s - 6) & 31));
                             dc1 = (int)((unsigned)(f1 * lsA) << ((s - 6) & 31));
                         } else {
@@ -277,6 +287,7 @@ __global__ __launch_bounds__(NW * 64) void recon_oct_kernel(ReconArgs a)
                             dc1 = (int)((unsigned)(f1 * lsA) + (1u << ((5 - s) & 31))) >> ((6 - s) & 31);
                         }
                     }
+MVHP_MARK("r_4x4");
                     const bool fast = __builtin_amdgcn_ballot_w64(shr != 0) == 0;   // shr = rnd = 0 from qP 24 up
 #pragma unroll
                     for (int sl = 0; sl < 2; sl++) {
@@ -311,6 +322,7 @@ __global__ __launch_bounds__(NW * 64) void recon_oct_kernel(ReconArgs a)
                     }
                 }
             }
+            MVHP_MARK("resid_store");
             if (kind == MVHP_KIND_I4x4) {   // lane-per-block -> lane-per-sample-pair goes through LDS (zeros without residual)
                 int32_t *dst = reinterpret_cast<int32_t *>(&Q.res[j * 32]);
                 *reinterpret_cast<int4 *>(dst) = make_int4(r2[0][0], r2[0][1], r2[0][2], r2[0][3]);
@@ -318,6 +330,7 @@ __global__ __launch_bounds__(NW * 64) void recon_oct_kernel(ReconArgs a)
                 *reinterpret_cast<int4 *>(dst + 8) = make_int4(r2[1][0], r2[1][1], r2[1][2], r2[1][3]);
                 *reinterpret_cast<int4 *>(dst + 12) = make_int4(r2[1][4], r2[1][5], r2[1][6], r2[1][7]);
             }
+            MVHP_MARK("resid_chroma");
             if (any_c) {
                 // ---- chroma 4x4 + transform_2x2_chromadc (h264_transform.c:827-860, :924-936, :988-1005) ----
                 const int pl = j >> 2, k = j & 3;
@@ -360,6 +373,7 @@ __global__ __launch_bounds__(NW * 64) void recon_oct_kernel(ReconArgs a)
             // =====================================================================================
             // wait for the row above: needs columns <= min(mbx+1, W-1); then fetch the top neighbours
             // =====================================================================================
+            MVHP_MARK("wait_up");
             if (Bv) {
                 const int need = up_base + min(mbx + 2, W);
                 int spins = 0;
@@ -389,6 +403,7 @@ __global__ __launch_bounds__(NW * 64) void recon_oct_kernel(ReconArgs a)
             // chroma prediction (h264_intra_prediction.c:2157-2564 + transform4x4_chroma): lane j predicts chroma
             // block j (plane j >> 2, block j & 3) -- all eight lanes of the octet
             // =====================================================================================
+            MVHP_MARK("pred_chroma");
             {
                 const int pl = j >> 2, k = j & 3;
                 const int cx = (k & 1) * 4, cy = (k >> 1) * 4;
@@ -438,8 +453,10 @@ __global__ __launch_bounds__(NW * 64) void recon_oct_kernel(ReconArgs a)
             // =====================================================================================
             // luma prediction
             // =====================================================================================
+            MVHP_MARK("pred_luma");
             if (kind == MVHP_KIND_I16x16) {
                 // h264_intra_prediction.c:1809-2141 + transform16x16_luma; lane j predicts its own two 4x4 blocks
+MVHP_MARK("p_i16");
                 uint32_t pw[2][4] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
                 if (i16mode == 0) {
                     if (Bv) {
@@ -487,6 +504,7 @@ __global__ __launch_bounds__(NW * 64) void recon_oct_kernel(ReconArgs a)
             } else if (kind == MVHP_KIND_I4x4) {
                 // Intra 4x4: 16 dependent block steps; lane j predicts samples (j&3, j>>2) and (j&3, (j>>2)+2) of the block.
                 // h264_intra_prediction.c:161-177, :315-483, :496-960 + transform4x4_luma (h264_transform.c:121-156).
+MVHP_MARK("p_i4_setup");
                 constexpr uint32_t X0 = (1u << 0) | (1u << 2) | (1u << 8) | (1u << 10);   // blocks with xO == 0
                 constexpr uint32_t Y0 = (1u << 0) | (1u << 1) | (1u << 4) | (1u << 5);    // blocks with yO == 0
                 const uint32_t av_left = A ? 0xffffu : (0xffffu & ~X0);
@@ -566,6 +584,7 @@ __global__ __launch_bounds__(NW * 64) void recon_oct_kernel(ReconArgs a)
                     Q.T[base + pix] = (uint8_t)two;
                     Q.T[base + pix + 64] = (uint8_t)(two >> 8);
                 };
+MVHP_MARK("p_i4_chain");
                 Ctl nA = fetch(0), nB = nA;
 #pragma unroll
                 for (int t = 0; t < 10; t++) {
@@ -585,6 +604,7 @@ __global__ __launch_bounds__(NW * 64) void recon_oct_kernel(ReconArgs a)
             } else {
                 // Intra 8x8: h264_intra_prediction.c:1107-1353 (edge filter) + :1366-1793 + transform8x8_luma;
                 // lane j predicts row j of the block
+MVHP_MARK("p_i8");
 #pragma unroll 1
                 for (int blk = 0; blk < 4; blk++) {
                     const int bxO = (blk & 1) * 8, byO = (blk >> 1) * 8;
@@ -666,6 +686,7 @@ __global__ __launch_bounds__(NW * 64) void recon_oct_kernel(ReconArgs a)
             // write-out (mb_to_rgb, export_utils.c:209-324, fused): lane j holds luma rows j, j+8 and chroma row j of
             // both planes; park, or flush the 4-macroblock strip
             // =====================================================================================
+            MVHP_MARK("writeout");
             {
                 const int mbi = mbx & 3;
                 const uint4 ya = *reinterpret_cast<const uint4 *>(&Q.T[(j + 1) * 32 + 16]);
@@ -695,6 +716,7 @@ __global__ __launch_bounds__(NW * 64) void recon_oct_kernel(ReconArgs a)
                     const uint2 *pra = reinterpret_cast<const uint2 *>(&Q.SC[1][(j >> 1) * 24]);
                     const uint2 *pbb = reinterpret_cast<const uint2 *>(&Q.SC[0][((j >> 1) + 4) * 24]);
                     const uint2 *prb = reinterpret_cast<const uint2 *>(&Q.SC[1][((j >> 1) + 4) * 24]);
+MVHP_MARK("w_full");
                     if (mbi == 3) {
                         // ---- full strip: exactly VM_STRIP store instructions ----
                         const uint2 b0 = ownb[0], b1 = ownb[1], b2 = ownb[2], q0 = ownr[0], q1 = ownr[1], q2 = ownr[2];
@@ -742,6 +764,7 @@ __global__ __launch_bounds__(NW * 64) void recon_oct_kernel(ReconArgs a)
 #undef MVHP_ST
                         n_st = VM_STRIP;
                     } else {
+MVHP_MARK("w_short");
                         // ---- short strip at the right picture edge (W % 4 != 0): compiler-counted stores ----
 #pragma unroll
                         for (int k = 0; k < 3; k++) {
@@ -778,6 +801,7 @@ __global__ __launch_bounds__(NW * 64) void recon_oct_kernel(ReconArgs a)
                         }
                     }
                 } else {
+MVHP_MARK("w_park");
                     // ---- park: luma rows in registers, chroma rows in the LDS strip ----
                     *reinterpret_cast<uint2 *>(&Q.SC[0][j * 24 + mbi * 8]) = cvb;
                     *reinterpret_cast<uint2 *>(&Q.SC[1][j * 24 + mbi * 8]) = cvr;
@@ -790,6 +814,7 @@ __global__ __launch_bounds__(NW * 64) void recon_oct_kernel(ReconArgs a)
             // =====================================================================================
             // neighbour state for the next macroblock / next row, then publish
             // =====================================================================================
+            MVHP_MARK("neighbours");
             {
                 // left columns: lane j luma rows j, j+8 and chroma row j of both planes; corners (old top-right sample) by
                 // lanes 0-2; bottom rows -> line buffer: lanes 0-3 luma, 4-5 Cb, 6-7 Cr (one dword each)
@@ -817,6 +842,7 @@ __global__ __launch_bounds__(NW * 64) void recon_oct_kernel(ReconArgs a)
                 if (j < 3) *kdst = kk;
                 *reinterpret_cast<uint32_t *>(bdst) = bot;
             }
+            MVHP_MARK("publish");
             done++;
             // LDS operations of one wave complete in order; the explicit wait makes the line-buffer
             // writes land before the counter without waiting for the global plane stores (vmcnt).

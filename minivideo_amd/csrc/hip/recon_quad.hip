@@ -180,7 +180,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_num_vgpr(100))) void
             const int cmode = (h0 >> 24) & 255, i16mode = h1 & 255;
             // Intra16x16 at QP'Y == 36 yields a non-zero DC term even from all-zero levels
             // (h264_transform.c:797-808), so the residual stage cannot be skipped there.
-            const bool quirk36 = (kind == MVHP_KIND_I16x16) && (qpy == 36);
+            const bool quirk36 = (kind == MVHP_KIND_I16x16) && (qpy == 36) && (a.dc_shift_from > 36);
             const bool need_l = ((nz & 0xffffu) != 0) || quirk36;
             const bool need_c = (nz & 0xff0000u) != 0;
             const bool any_l = __builtin_amdgcn_ballot_w64(need_l) != 0;
@@ -275,7 +275,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_num_vgpr(100))) void
                         const int bP = (base | (j & ~10) | ((j >> 2) & 2)) << 2;
                         const int f = had4_lanes(g, dpp_quad<DPP_XOR2>(g), ci, bP, bP | (8 << 2));
                         const int lsA = B.ls0[qpy];
-                        if (qpy > 36) dc = (int)((unsigned)(f * lsA) << ((s - 6) & 31));
+                        if (qpy >= a.dc_shift_from) dc = (int)((unsigned)(f * lsA) << ((s - 6) & 31));
                         else dc = (int)((unsigned)(f * lsA) + (1u << ((5 - s) & 31))) >> ((6 - s) & 31);
                     }
                     // quant4x4, h264_transform.c:1100-1134: ((c*LS + rnd) >> shr) << shl, the left shift folded into LS;

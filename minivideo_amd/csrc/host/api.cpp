@@ -313,7 +313,8 @@ minivideo_EXPORT int minivideo_parse(MediaFile_t *m, const bool extract_audio, c
     if (!read_whole_file(m, buf)) { log_err("Unable to read the media file"); return FAILURE; }
     if (m->container == CONTAINER_MP4) return parse_mp4_track(m, buf);
     std::vector<h264::EsSample> samples;
-    if (h264::index_annexb(buf.data(), buf.size(), samples) != h264::RC_SUCCESS) {
+    const bool spec = getenv("MINIVIDEO_SPEC") && atoi(getenv("MINIVIDEO_SPEC")) != 0;   // opt-in, SURVEY 8f row f4
+    if ((spec ? h264::index_annexb_spec(buf.data(), buf.size(), samples) : h264::index_annexb(buf.data(), buf.size(), samples)) != h264::RC_SUCCESS) {
         log_err("No NAL Unit have been found in this bitstream!");
         return FAILURE;
     }
@@ -365,6 +366,8 @@ minivideo_EXPORT int minivideo_decode(MediaFile_t *m, const char *output_directo
     mvhp_stream s;
     s.data = buf.data();
     s.size = buf.size();
+    // opt-in: index and reconstruct by the standard instead of by the reference's quirks
+    if (const char *e = getenv("MINIVIDEO_SPEC")) s.spec = atoi(e) != 0;
     std::string err;
     const int brc = (m->container == CONTAINER_MP4) ? s.build_mp4(err) : s.build(err);
     if (brc != h264::RC_SUCCESS) { log_err("%s", err.c_str()); return FAILURE; }

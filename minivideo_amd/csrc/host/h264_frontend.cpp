@@ -54,6 +54,42 @@ int index_annexb(const uint8_t *data, size_t size, std::vector<EsSample> &out)
     return RC_SUCCESS;
 }
 
+// The standard's byte stream format (Annex B.1): a NAL unit starts behind 00 00 01 (any number of zero bytes in front)
+// and ends at the next 00 00 00 / 00 00 01 or at the end of the stream; slice (5), SPS (7) and PPS (8) NAL units are
+// kept whatever their nal_ref_idc.  SURVEY 8f row f4: outside the parity contract -- the reference needs four-byte start
+// codes, nal_ref_idc = 3 and 32 bytes behind the last NAL unit (esparser.c:65-82).
+int index_annexb_spec(const uint8_t *data, size_t size, std::vector<EsSample> &out)
+{
+    out.clear();
+    if (!data) return RC_FAILURE;
+    size_t i = 0;
+    while (i + 3 < size) {
+        if (!(data[i] == 0 && data[i + 1] == 0 && data[i + 2] == 1)) { i++; continue; }
+        const size_t beg = i + 3;
+        size_t end = size;
+        for (size_t p = beg; p + 2 < size; p++)
+            if (data[p] == 0 && data[p + 1] == 0 && data[p + 2] <= 1) { end = p; break; }
+        const uint8_t nb = data[beg];
+        const int type = nb & 31;
+        if (!(nb & 0x80) && (type == 5 || type == 7 || type == 8) && end > beg) {
+            EsSample s;
+            s.offset = beg;
+            s.nal_unit_type = type;
+            s.nal_ref_idc = (nb >> 5) & 3;
+            s.is_idr = (type == 5);
+            size_t e = end;
+            while (e > beg + 1 && data[e - 1] == 0) e--;   // trailing_zero_8bits
+            s.nal_size = e - beg;
+            if (!out.empty()) out.back().sample_size = s.offset - out.back().offset;
+            out.push_back(s);
+        }
+        i = end > beg ? end : beg;
+    }
+    if (out.empty()) return RC_FAILURE;
+    out.back().sample_size = size - out.back().offset;
+    return RC_SUCCESS;
+}
+
 // H4: emulation prevention removal (h264_nalu.c:195-249)
 void unescape_rbsp(const uint8_t *src, size_t n, std::vector<uint8_t> &dst)
 {

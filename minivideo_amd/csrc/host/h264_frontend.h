@@ -72,6 +72,8 @@ struct EsSample {
 };
 
 int  index_annexb(const uint8_t *data, size_t size, std::vector<EsSample> &out);
+// Annex B as the standard defines it (MVHP_STREAM_SPEC): 3- or 4-byte start codes, any nal_ref_idc, scan to the end
+int  index_annexb_spec(const uint8_t *data, size_t size, std::vector<EsSample> &out);
 void unescape_rbsp(const uint8_t *src, size_t n, std::vector<uint8_t> &dst);
 int  parse_sps(BitReader &br, Sps &sps, std::string &err);
 int  parse_pps(BitReader &br, const Sps *sps_table /*[32]*/, Pps &pps, std::string &err);

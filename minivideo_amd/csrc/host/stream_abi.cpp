@@ -22,7 +22,7 @@ static bool slice_can_hold_picture(const Sps &sps, size_t nal_size)
 
 int mvhp_stream::build(std::string &err)
 {
-    if (index_annexb(data, size, samples) != RC_SUCCESS) { err = "no NAL unit found in the bitstream"; return RC_FAILURE; }
+    if ((spec ? index_annexb_spec(data, size, samples) : index_annexb(data, size, samples)) != RC_SUCCESS) { err = "no NAL unit found in the bitstream"; return RC_FAILURE; }
     Sps sps_tab[32];
     Pps pps_tab[256];
     std::vector<uint8_t> rbsp;
@@ -43,7 +43,7 @@ int mvhp_stream::build(std::string &err)
         } else if (s.nal_unit_type == 5) {
             Idr idr;
             idr.sample = i;
-            br.ue(); // first_mb_in_slice
+            const unsigned first_mb = br.ue(); // first_mb_in_slice (the reference ignores it, h264_slice.c:1019)
             br.ue(); // slice_type
             const unsigned pid = br.ue();
             if (pid < 256 && pps_tab[pid].valid && sps_tab[pps_tab[pid].sps_id].valid) {
@@ -51,6 +51,12 @@ int mvhp_stream::build(std::string &err)
                 idr.sps = sps_tab[idr.pps.sps_id];
                 idr.ok = slice_can_hold_picture(idr.sps, s.nal_size);
                 if (!idr.ok) idr.why = "slice NAL too small for the picture size of its SPS";
+                if (spec && first_mb != 0) {   // a further slice of the previous picture: not a picture of its own
+                    idr.ok = false;
+                    idr.why = "pictures of several slices are not supported (one slice per picture)";
+                    if (!idrs.empty() && idrs.back().ok) { idrs.back().ok = false; idrs.back().why = idr.why; }
+                    continue;
+                }
             } else {
                 idr.why = "slice refers to a parameter set that was not (successfully) received";
             }
@@ -156,6 +162,19 @@ MVHP_EXPORT int mvhp_stream_open(const uint8_t *data, size_t size, mvhp_stream_t
     return MVHP_SUCCESS;
 }
 
+MVHP_EXPORT int mvhp_stream_open_ex(const uint8_t *data, size_t size, uint32_t flags, mvhp_stream_t **out)
+{
+    if (!out || !data || (flags & ~MVHP_STREAM_SPEC)) return MVHP_FAILURE;
+    *out = nullptr;
+    mvhp_stream *s = new mvhp_stream();
+    s->data = data;
+    s->size = size;
+    s->spec = (flags & MVHP_STREAM_SPEC) != 0;
+    if (s->build(g_stream_err) != RC_SUCCESS) { delete s; return MVHP_FAILURE; }
+    *out = s;
+    return MVHP_SUCCESS;
+}
+
 MVHP_EXPORT int mvhp_stream_open_mp4(const uint8_t *data, size_t size, mvhp_stream_t **out)
 {
     if (!out || !data) return MVHP_FAILURE;
@@ -180,7 +199,7 @@ MVHP_EXPORT int mvhp_stream_params(const mvhp_stream_t *s, int idr, mvhp_stream_
     out->height_mbs = (uint32_t)i.sps.height_map_units;
     out->chroma_qp_index_offset = i.pps.chroma_qp_index_offset;
     out->second_chroma_qp_index_offset = i.pps.second_chroma_qp_index_offset;
-    out->flags = i.pps.transform_8x8_mode ? MVHP_PARAM_MAY_HAVE_8X8 : 0u;
+    out->flags = (i.pps.transform_8x8_mode ? MVHP_PARAM_MAY_HAVE_8X8 : 0u) | (s->spec ? MVHP_PARAM_SPEC_LUMA_DC : 0u);
     return MVHP_SUCCESS;
 }
 

@@ -18,6 +18,7 @@ struct mvhp_stream {
     std::vector<h264::EsSample> samples;
     std::vector<Idr> idrs;
     int param_errors = 0;
+    bool spec = false;            // MVHP_STREAM_SPEC: standard-conformant index + luma-DC rule (opt-in, outside parity)
 
     int build(std::string &err);      // Annex-B elementary stream
     int build_mp4(std::string &err);  // ISO-BMFF: avcC parameter sets + length-prefixed NAL units of the sync samples

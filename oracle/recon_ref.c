@@ -96,6 +96,7 @@ typedef struct {
     int pitch, cpitch;        /* plane pitches  */
     uint8_t *y, *cb, *cr;
     int cqp_off[2];
+    int dc_shift_from;        /* 37 = reference (`qP > 36`), 36 = standard (MVHP_PARAM_SPEC_LUMA_DC) */
     int mbx, mby;             /* current macroblock */
 } pic_t;
 
@@ -258,7 +259,7 @@ static void residual8x8(const int c[8][8], int qP, int r[8][8])
 /* transform_16x16_lumadc, h264_transform.c:756-812 -- including the
  * `qP > 36` test (the standard says >= 36): at QP'Y == 36 the reference
  * evaluates (f*LS + (1 << -1)) >> 0. */
-static void luma_dc(const int c[4][4], int qP, int dcY[4][4])
+static void luma_dc(const int c[4][4], int qP, int shift_from, int dcY[4][4])
 {
     static const int H4[4][4] = {{1, 1, 1, 1}, {1, 1, -1, -1}, {1, -1, -1, 1}, {1, -1, 1, -1}};
     int f1[4][4] = {{0}}, f2[4][4] = {{0}}, i, j, k;
@@ -271,7 +272,7 @@ static void luma_dc(const int c[4][4], int qP, int dcY[4][4])
         for (j = 0; j < 4; j++)
             for (k = 0; k < 4; k++)
                 f2[i][j] += f1[i][k] * H4[k][j];
-    if (qP > 36) {
+    if (qP >= shift_from) {   /* 37: the reference's `qP > 36`; 36: the standard (MVHP_PARAM_SPEC_LUMA_DC, opt-in) */
         for (i = 0; i < 4; i++)
             for (j = 0; j < 4; j++)
                 dcY[i][j] = wshl(f2[i][j] * ls, s - 6);
@@ -620,7 +621,7 @@ static void recon_i16x16(pic_t *p, const mvhp_mb_header_t *h, const int16_t *coe
         blk4_xy(blk, &xO, &yO);
         c1[yO / 4][xO / 4] = coef[blk * 16];
     }
-    luma_dc(c1, h->qp_y, dcY);
+    luma_dc(c1, h->qp_y, p->dc_shift_from, dcY);
     for (blk = 0; blk < 16; blk++) {
         int xO, yO, c[4][4], r[4][4];
         blk4_xy(blk, &xO, &yO);
@@ -716,6 +717,7 @@ ORC_EXPORT int orc_recon_frame(const mvhp_stream_params_t *sp, const void *packe
     p.cr = p.cb + (size_t)W * 8 * H * 8;
     p.cqp_off[0] = sp->chroma_qp_index_offset;
     p.cqp_off[1] = sp->second_chroma_qp_index_offset;
+    p.dc_shift_from = (sp->flags & MVHP_PARAM_SPEC_LUMA_DC) ? 36 : 37;
     for (mb = 0; mb < W * H; mb++) {
         mvhp_mb_header_t h;
         int16_t coef[MVHP_MB_COEFS];

@@ -7,12 +7,14 @@ from minivideo_amd.hotpath import StreamParams, lib
 
 
 class Stream:
-    def __init__(self, data):
+    def __init__(self, data, spec=False):
         self.L = lib()
         self.L.mvhp_stream_last_error.restype = C.c_char_p
+        self.L.mvhp_stream_open_ex.restype = C.c_int
+        self.L.mvhp_stream_open_ex.argtypes = [C.c_void_p, C.c_size_t, C.c_uint32, C.POINTER(C.c_void_p)]
         self.data = np.ascontiguousarray(data, dtype=np.uint8)
         self.h = C.c_void_p()
-        self.ok = self.L.mvhp_stream_open(self.data.ctypes.data, self.data.size, C.byref(self.h)) == 1
+        self.ok = self.L.mvhp_stream_open_ex(self.data.ctypes.data, self.data.size, 1 if spec else 0, C.byref(self.h)) == 1
 
     def close(self):
         if self.h:
