@@ -185,9 +185,11 @@ static int pick_layout(const mvhp_ctx *c, const mvhp_stream_params_t *p, int n_f
         // against the one-picture kernel on 1080p: between 512 and 768 pictures
         layout = (n_frames >= 3 * c->n_cus) ? MVHP_LAYOUT_QUAD : MVHP_LAYOUT_ROWS;
         // eight pictures per workgroup (one 8-wave workgroup per CU) from 8 * CUs pictures: fewer instructions per
-        // macroblock and full-line writes; measured 1.18x the four-picture kernel with RGB output, equal without
-        // (Intra8x8-heavy batches run faster on the four-picture kernel: 1.21 vs 1.11 x 10^9 MB/s)
-        if (n_frames >= 8 * c->n_cus && !(p->flags & MVHP_PARAM_MAY_HAVE_8X8)) layout = MVHP_LAYOUT_OCT;
+        // macroblock and full-line writes; measured 1.16x the four-picture kernel on Baseline content with RGB output and
+        // 1.03x on High content (Intra8x8: 12.8 vs 13.2 ms per 2048 x 1080p).  Only while its eight waves fit into LDS
+        // (pictures up to 156 macroblocks wide): with six waves it loses to the four-picture kernel (2160p High, 2048
+        // pictures: 0.99 vs 1.29 x 10^9 MB/s).
+        if (n_frames >= 8 * c->n_cus && mvhp::recon_oct_lds_bytes((int)p->width_mbs, 8) <= c->max_lds) layout = MVHP_LAYOUT_OCT;
     }
     // the batch kernels address a workgroup's pictures with 32-bit offsets and keep one line buffer per picture in LDS
     const size_t mbs = (size_t)p->width_mbs * p->height_mbs;

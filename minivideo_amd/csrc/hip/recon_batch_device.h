@@ -146,6 +146,52 @@ __device__ __forceinline__ void rgb16(const uint4 yv, const uint2 cbv, const uin
     o2 = v4i{d[8], d[9], d[10], d[11]};
 }
 
+// The same split in two: the chroma terms of a pair of chroma samples (four luma samples wide), and their use on one
+// luma word.  Two luma rows share a chroma row (export_utils.c:278-279), so a lane that owns rows 2j and 2j+1 computes
+// the terms once.
+struct RgbTerms {
+    s16x2 rtl, rth, gtl, gth, btl, bth;
+};
+__device__ __forceinline__ RgbTerms rgb_terms(u16x2 cb, u16x2 cr)
+{
+    const s16x2 rt = __builtin_bit_cast(s16x2, (u16x2)((cr * (unsigned short)204) >> 7)) - (short)222;
+    const s16x2 gt = (short)135 - __builtin_bit_cast(s16x2, (u16x2)((cb * (unsigned short)100) >> 8)) -
+                     __builtin_bit_cast(s16x2, (u16x2)((cr * (unsigned short)208) >> 8));
+    const s16x2 bt = __builtin_bit_cast(s16x2, (u16x2)((cb * (unsigned short)129) >> 6)) - (short)276;
+    RgbTerms t;
+    t.rtl = __builtin_shufflevector(rt, rt, 0, 0); t.rth = __builtin_shufflevector(rt, rt, 1, 1);
+    t.gtl = __builtin_shufflevector(gt, gt, 0, 0); t.gth = __builtin_shufflevector(gt, gt, 1, 1);
+    t.btl = __builtin_shufflevector(bt, bt, 0, 0); t.bth = __builtin_shufflevector(bt, bt, 1, 1);
+    return t;
+}
+__device__ __forceinline__ void rgb4_apply(uint32_t yw, const RgbTerms &t, int &d0, int &d1, int &d2)
+{
+    const s16x2 ly01 = __builtin_bit_cast(s16x2, (u16x2)((bytes01(yw) * (unsigned short)149) >> 7));
+    const s16x2 ly23 = __builtin_bit_cast(s16x2, (u16x2)((bytes23(yw) * (unsigned short)149) >> 7));
+    const uint32_t RA = sat_pk_u8v(ly01 + t.rtl), GA = sat_pk_u8v(ly01 + t.gtl), BA = sat_pk_u8v(ly01 + t.btl);
+    const uint32_t RB = sat_pk_u8v(ly23 + t.rth), GB = sat_pk_u8v(ly23 + t.gth), BB = sat_pk_u8v(ly23 + t.bth);
+    const uint32_t W1 = GA | (BA << 16), W2 = RB | (GB << 16);
+    d0 = (int)__builtin_amdgcn_perm(W1, RA, 0x01060400u);   // R0 G0 B0 R1
+    d1 = (int)__builtin_amdgcn_perm(W2, W1, 0x06040301u);   // G1 B1 R2 G2
+    d2 = (int)__builtin_amdgcn_perm(BB, W2, 0x05030104u);   // B2 R3 G3 B3
+}
+// two luma rows of 16 samples over one chroma row -> 2 x 48 bytes of RGB
+__device__ __forceinline__ void rgb16x2(const uint4 ya, const uint4 yb, const uint2 cbv, const uint2 crv, v4i &a0, v4i &a1,
+                                        v4i &a2, v4i &b0, v4i &b1, v4i &b2)
+{
+    int da[12], db[12];
+    const uint32_t yaw[4] = {ya.x, ya.y, ya.z, ya.w}, ybw[4] = {yb.x, yb.y, yb.z, yb.w};
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+        const uint32_t cbw = (g < 2) ? cbv.x : cbv.y, crw = (g < 2) ? crv.x : crv.y;
+        const RgbTerms t = (g & 1) ? rgb_terms(bytes23(cbw), bytes23(crw)) : rgb_terms(bytes01(cbw), bytes01(crw));
+        rgb4_apply(yaw[g], t, da[3 * g], da[3 * g + 1], da[3 * g + 2]);
+        rgb4_apply(ybw[g], t, db[3 * g], db[3 * g + 1], db[3 * g + 2]);
+    }
+    a0 = v4i{da[0], da[1], da[2], da[3]}; a1 = v4i{da[4], da[5], da[6], da[7]}; a2 = v4i{da[8], da[9], da[10], da[11]};
+    b0 = v4i{db[0], db[1], db[2], db[3]}; b1 = v4i{db[4], db[5], db[6], db[7]}; b2 = v4i{db[8], db[9], db[10], db[11]};
+}
+
 // Plane-prediction gradient (h264_intra_prediction.c:2064-2080, :2491-2504): sum over i of (i+1) * (e[h+i] - e[h-2-i])
 // with e[-1] = the corner, for 16 edge samples (h = 8, i < 8) as four byte dot products.
 __device__ __forceinline__ int plane_grad16(const uint4 e, uint32_t cor)

@@ -13,7 +13,7 @@
 //   * everything that is paid once per step (header decoding, the row-above wait, neighbour bookkeeping) is shared
 //     by eight macroblocks.
 // Lane j of an octet owns luma 4x4 blocks 2j and 2j+1 (64 contiguous bytes of the record: for an Intra8x8 macroblock
-// the same bytes are rows 4(j&1)..+3 of 8x8 block j>>1), chroma block j, luma rows j and j+8 and chroma row j of
+// the same bytes are rows 4(j&1)..+3 of 8x8 block j>>1), chroma block j, luma rows 2j and 2j+1 and chroma row j of
 // both planes of the finished macroblock.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -28,6 +28,61 @@ namespace mvhp {
 #ifndef MVHP_LOAD_HINT
 #define MVHP_LOAD_HINT ""   // cache-policy suffix of the record loads (measurement builds try " nt")
 #endif
+// The eight-picture kernel's LDS block per picture and wave: QLds (recon_batch_device.h) with the filtered Intra8x8
+// edge kept as three 28-entry arrays -- G[0][k] = p'[k] (the unified edge EE of recon_device.h mode_entry(): 0-1 left[7]
+// replicated, 2-9 left[7..0], 10 corner, 11-26 top[0..15], 27 top[15] replicated), G[1][k] = (p'[k] + p'[k+1] + 1) >> 1,
+// G[2][k] = (p'[k] + 2 p'[k+1] + p'[k+2] + 2) >> 2 -- so that a predicted sample is ONE byte read, whatever the mode.
+struct __attribute__((aligned(16))) OLds {
+    union {
+        int32_t scr[128];    // (unused by this kernel: the 8x8 column pass exchanges registers between lane pairs)
+        int16_t res[256];    // Intra4x4: [blk][sample pair] ; Intra8x8: [blk8][row][column]
+    };
+    uint8_t T[17 * 32 + 16]; // luma tile, as QLds
+    uint8_t TC[2][9 * 16];   // chroma tiles, as QLds
+    uint8_t Lcol[16];        // compact left neighbour column (luma)
+    uint8_t LcolC[2][8];     // compact left neighbour columns (Cb, Cr)
+    uint8_t G[3][32];        // Intra8x8: filtered edge arrays of the block being predicted
+    uint8_t Lc8[8];          // Intra8x8: right column of 8x8 block 0 / 2 = left neighbours of block 1 / 3
+    uint8_t pad8[8];
+    uint8_t SC[2][8 * 24];   // output strip, chroma rows of the three parked macroblocks
+#ifdef MVHP_OLDS_PAD
+    uint8_t pad[MVHP_OLDS_PAD];   // measurement builds: bank offset between the pictures of a wavefront
+#endif
+};
+#ifndef MVHP_OLDS_PAD
+static_assert(sizeof(OLds) == 1888, "OLds layout");
+#endif
+
+struct __attribute__((aligned(16))) OTables {
+    int      progress[16];
+    int      abort_flag;
+    int      pad[3];
+    int4     q4[52];         // as QTables
+    int      ls0[52];
+    int      ls8[36];
+    uint8_t  qpc[64];
+    uint32_t tap4[2 * 9 * 16];
+    uint8_t  tap8b[9 * 64];  // Intra8x8 [mode][y][x]: array * 32 + index into OLds::G
+};
+
+// tap8b entry: which of the three edge arrays, and where (mode_entry: type 0 = p'[k], 1 = two taps, 2 = three taps)
+static __device__ uint8_t tap8b_entry(int mode, int x, int y)
+{
+    const int e = mode_entry(8, mode, x, y), k = e & 31, t = e >> 5;
+    return (uint8_t)(t * 32 + min(k, 27));
+}
+
+// (a >> 6, b >> 6) packed: saturate to int16 first, then one packed shift -- exact for the reconstructed sample, as in
+// idct4x4_packed (recon_device.h): a value beyond int16 means |r| >= 511, where clip255(pred + r) no longer depends on r
+__device__ __forceinline__ int pack_res_shr6(int a, int b)
+{
+    typedef short short2_t __attribute__((ext_vector_type(2)));
+    const short2_t v = __builtin_amdgcn_cvt_pk_i16(a, b);
+    return __builtin_bit_cast(int, (short2_t)(v >> (short)6));
+}
+
+__device__ __forceinline__ uint32_t lerp_u8(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_lerp(a, b, c); }
+
 #ifdef MVHP_MARKS   // measurement builds: section markers that survive into the ISA text (tools/isa_sections.py)
 #define MVHP_MARK(name) asm volatile("; MARK " name ::: "memory")
 #else
@@ -45,11 +100,11 @@ __global__ __launch_bounds__(NW * 64) void recon_oct_kernel(ReconArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int W = a.width_mbs, H = a.height_mbs;
-    QTables &B = *reinterpret_cast<QTables *>(smem);
-    uint8_t *lines = smem + sizeof(QTables);              // [octet][ luma W*16 | Cb W*8 | Cr W*8 ]
+    OTables &B = *reinterpret_cast<OTables *>(smem);
+    uint8_t *lines = smem + sizeof(OTables);              // [octet][ luma W*16 | Cb W*8 | Cr W*8 ]
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane_c = threadIdx.x & 63;
-    uint8_t *wave_lds = lines + (size_t)8 * W * 32 + (size_t)wave * 8 * sizeof(QLds);
+    uint8_t *wave_lds = lines + (size_t)8 * W * 32 + (size_t)wave * 8 * sizeof(OLds);
 
     // ---- one-time table setup (as recon_quad.hip) ----
     for (int i = threadIdx.x; i < 52; i += NW * 64) {
@@ -67,7 +122,7 @@ __global__ __launch_bounds__(NW * 64) void recon_oct_kernel(ReconArgs a)
     for (int i = threadIdx.x; i < 64; i += NW * 64) B.qpc[i] = (uint8_t)((i < 30) ? i : c_qpc[min(i, 51) - 30]);
     for (int i = threadIdx.x; i < 2 * 9 * 16; i += NW * 64)
         B.tap4[i] = tap4_entry((i >> 4) % 9, i & 3, (i >> 2) & 3, i >= 9 * 16);
-    for (int i = threadIdx.x; i < 9 * 64; i += NW * 64) B.tap8[i] = tap8_entry(i >> 6, i & 7, (i >> 3) & 7);
+    for (int i = threadIdx.x; i < 9 * 64; i += NW * 64) B.tap8b[i] = tap8b_entry(i >> 6, i & 7, (i >> 3) & 7);
     if (threadIdx.x < 16) B.progress[threadIdx.x] = 0;
     if (threadIdx.x == 16) B.abort_flag = 0;
     __syncthreads();
@@ -131,7 +186,7 @@ __global__ __launch_bounds__(NW * 64) void recon_oct_kernel(ReconArgs a)
     const int up_adj = __builtin_amdgcn_readfirstlane((wave == 0) ? -1 : 0); // wave 0 follows the last wave's previous pass
     int done = 0;  // macroblocks completed by this wave
     int n_st = 0;  // asm stores the previous step issued behind its prefetch (0 also when the compiler counted them)
-    // output strip: luma rows j and j+8 of three parked macroblocks (registers); their chroma rows live in LDS (Q.SC)
+    // output strip: luma rows 2j and 2j+1 of three parked macroblocks (registers); their chroma rows live in LDS (Q.SC)
     v4i st_a0 = {0, 0, 0, 0}, st_a1 = st_a0, st_a2 = st_a0, st_b0 = st_a0, st_b1 = st_a0, st_b2 = st_a0;
 
     for (int row = wave; row < H; row += NW) {
@@ -143,7 +198,7 @@ __global__ __launch_bounds__(NW * 64) void recon_oct_kernel(ReconArgs a)
             int lane = lane_c;
             asm volatile("" : "+v"(lane));   // re-materialised per macroblock: keeps lane-dependent addresses out of registers
             const int o = lane >> 3, j = lane & 7;
-            QLds &Q = *reinterpret_cast<QLds *>(wave_lds + o * sizeof(QLds));
+            OLds &Q = *reinterpret_cast<OLds *>(wave_lds + o * sizeof(OLds));
             uint8_t *line_y = lines + (size_t)o * W * 32;
             uint8_t *line_cb = line_y + W * 16;
             uint8_t *line_cr = line_cb + W * 8;
@@ -213,52 +268,50 @@ MVHP_MARK("r_8x8");
                     const int hh = j & 1;
                     const int *l8 = &B.ls8[m * 6];
                     const int ls0 = l8[0], ls1 = l8[1], ls2 = l8[2], ls3 = l8[3], ls4 = l8[4], ls5 = l8[5];
+                    // quant8x8 (:1256-1284) as ONE form for both branches: (level * LS' + rnd') >> shr' with
+                    // qP >= 36: LS' = LS << (qP/6 - 6), rnd' = 0, shr' = 0;  else: LS' = LS, rnd' = 2^(5 - qP/6), shr' = 6 - qP/6
+                    const int shl8 = max(s - 6, 0), shr8 = max(6 - s, 0), rnd8 = (1 << shr8) >> 1;
+                    const int q0 = ls0 << shl8, q1 = ls1 << shl8, q2 = ls2 << shl8, q3 = ls3 << shl8, q4 = ls4 << shl8, q5 = ls5 << shl8;
                     int dr[4][8];
 #pragma unroll
                     for (int t = 0; t < 4; t++) {   // row 4*hh + t: its class pattern (h264.c:438-446) depends on t only
                         const int pkw[4] = {w[4 + 2 * t].x, w[4 + 2 * t].y, w[5 + 2 * t].x, w[5 + 2 * t].y};
-                        const int k0 = (t == 0) ? ls0 : (t == 2) ? ls4 : ls3;   // columns 0, 4
-                        const int k1 = (t == 0) ? ls3 : (t == 2) ? ls5 : ls1;   // odd columns
-                        const int k2 = (t == 0) ? ls4 : (t == 2) ? ls2 : ls5;   // columns 2, 6
+                        const int k0 = (t == 0) ? q0 : (t == 2) ? q4 : q3;   // columns 0, 4
+                        const int k1 = (t == 0) ? q3 : (t == 2) ? q5 : q1;   // odd columns
+                        const int k2 = (t == 0) ? q4 : (t == 2) ? q2 : q5;   // columns 2, 6
 #pragma unroll
                         for (int c = 0; c < 8; c++) {
                             const int lv = (c & 1) ? (pkw[c >> 1] >> 16) : (int)(short)(pkw[c >> 1] & 0xffff);
                             const int ls = (c & 1) ? k1 : ((c & 3) == 0 ? k0 : k2);
-                            if (qpy > 35) dr[t][c] = (int)((unsigned)(lv * ls) << ((s - 6) & 31));
-                            else dr[t][c] = (lv * ls + (1 << ((5 - s) & 31))) >> ((6 - s) & 31);
+                            dr[t][c] = (__mul24(lv, ls) + rnd8) >> shr8;
                         }
                     }
                     if (hh == 0) dr[0][0] += 32; // rounding term of the final (m + 32) >> 6, see idct4x4
 #pragma unroll
                     for (int t = 0; t < 4; t++) idct8_1d(dr[t]);
-                    int col[2][2][8];
+                    // Column pass: the two lanes of a block (rows 0-3 / rows 4-7) swap half of what they hold (DPP, lane ^ 1),
+                    // after which the even lane has columns 0-3 and the odd lane columns 4-7 of all eight rows.
+                    int colv[4][8];   // [column of this lane's half][row]
 #pragma unroll
-                    for (int h = 0; h < 2; h++) {
-                        if ((j >> 2) == h) {
-                            int32_t *dst = &Q.scr[((j >> 1) & 1) * 64 + hh * 32];
+                    for (int t = 0; t < 4; t++) {
 #pragma unroll
-                            for (int t = 0; t < 4; t++) {
-                                *reinterpret_cast<int4 *>(dst + t * 8) = make_int4(dr[t][0], dr[t][1], dr[t][2], dr[t][3]);
-                                *reinterpret_cast<int4 *>(dst + t * 8 + 4) = make_int4(dr[t][4], dr[t][5], dr[t][6], dr[t][7]);
-                            }
+                        for (int c = 0; c < 4; c++) {
+                            const int send = hh ? dr[t][c] : dr[t][c + 4];
+                            const int keep = hh ? dr[t][c + 4] : dr[t][c];
+                            const int recv = dpp_quad<DPP_XOR1>(send);
+                            colv[c][t] = hh ? recv : keep;         // rows 0-3
+                            colv[c][t + 4] = hh ? keep : recv;     // rows 4-7
                         }
-                        WAVE_SYNC();
-#pragma unroll
-                        for (int i = 0; i < 8; i++) {
-                            const int2 v = *reinterpret_cast<const int2 *>(&Q.scr[(j >> 2) * 64 + i * 8 + (j & 3) * 2]);
-                            col[h][0][i] = v.x;
-                            col[h][1][i] = v.y;
-                        }
-                        idct8_1d(col[h][0]);
-                        idct8_1d(col[h][1]);
-                        WAVE_SYNC();
                     }
-                    // res[blk8][row][column] (int16): lane j columns 2*(j&3), +1 of block 2h + (j >> 2)
 #pragma unroll
-                    for (int h = 0; h < 2; h++) {
-                        int32_t *dst = reinterpret_cast<int32_t *>(&Q.res[(2 * h + (j >> 2)) * 64 + (j & 3) * 2]);
+                    for (int c = 0; c < 4; c++) idct8_1d(colv[c]);
+                    // res[blk8][row][column] (int16): this lane's four columns of every row = one 8-byte store per row
+                    {
+                        int16_t *dst = &Q.res[(j >> 1) * 64 + hh * 4];
 #pragma unroll
-                        for (int i = 0; i < 8; i++) dst[i * 4] = pack_res(col[h][0][i] >> 6, col[h][1][i] >> 6);
+                        for (int i = 0; i < 8; i++)
+                            *reinterpret_cast<int2 *>(dst + i * 8) = make_int2(pack_res_shr6(colv[0][i], colv[1][i]),
+                                                                               pack_res_shr6(colv[2][i], colv[3][i]));
                     }
                 } else {
                     // ---- luma 4x4 (transform_4x4_residual, h264_transform.c:1049-1191), two blocks per lane ----
@@ -613,62 +666,80 @@ MVHP_MARK("p_i8");
                     const bool up = (byO > 0) || Bv;
                     const bool upleft = (bxO > 0) ? ((byO > 0) || Bv) : ((byO > 0) ? A : D);
                     const bool upright = (blk == 0) ? Bv : (blk == 1) ? C : (blk == 2);
+                    // ---- raw edge, the same for the eight lanes of the picture: 16 samples above (tile row byO), the
+                    //      corner, 8 samples to the left (compact columns) ----
                     const uint8_t *Trow = &Q.T[byO * 32 + 16 + bxO];
-                    const uint8_t *Tcol = &Q.T[(byO + 1) * 32 + 15 + bxO];
+                    const uint2 tA = *reinterpret_cast<const uint2 *>(Trow);
+                    uint2 tB = *reinterpret_cast<const uint2 *>(Trow + 8);
+                    const uint32_t cw = *reinterpret_cast<const uint32_t *>(Trow - 4);            // byte 3 = p[-1,-1]
+                    const uint2 lf = *reinterpret_cast<const uint2 *>(bxO ? Q.Lc8 : &Q.Lcol[byO]); // p[-1,0..7]
+                    if (!upright) tB.x = tB.y = __builtin_amdgcn_perm(0u, tA.y, 0x03030303u);      // p[8..15,-1] = p[7,-1] (:1230-1236)
+                    // the unified edge sequence (28 entries, ends replicated) as seven words
+                    uint32_t Wd[7];
+                    Wd[0] = __builtin_amdgcn_perm(0u, lf.y, 0x02030303u);                          // L7 L7 L7 L6
+                    Wd[1] = __builtin_amdgcn_perm(lf.y, lf.x, 0x02030405u);                        // L5 L4 L3 L2
+                    Wd[2] = __builtin_amdgcn_perm(cw, __builtin_amdgcn_perm(tA.x, lf.x, 0x040c0001u), 0x03070100u); // L1 L0 C T0
+                    Wd[3] = __builtin_amdgcn_alignbyte(tA.y, tA.x, 1);                             // T1..T4
+                    Wd[4] = __builtin_amdgcn_alignbyte(tB.x, tA.y, 1);                             // T5..T8
+                    Wd[5] = __builtin_amdgcn_alignbyte(tB.y, tB.x, 1);                             // T9..T12
+                    Wd[6] = __builtin_amdgcn_perm(0u, tB.y, 0x03030201u);                          // T13 T14 T15 T15
+                    // Intra_8x8_sample_filtering (:1295-1353): p'[k] = (s[k-1] + 2 s[k] + s[k+1] + 2) >> 2 on that sequence
+                    // = lerp_up(lerp_down(s[k-1], s[k+1]), s[k]) per byte; where the corner or a whole side is missing the
+                    // neighbour is the sample itself (the reference's special cases), patched into word 2
+                    const uint32_t selP = 0x03020100u + (left ? 0u : 0x00040000u) + (upleft ? 0u : 0x04000000u);
+                    const uint32_t selN = 0x03020100u + (upleft ? 0u : 0x00000400u) + (up ? 0u : 0x00040000u);
+                    uint32_t Ed[8];
 #pragma unroll
-                    for (int part = 0; part < 4; part++) {
-                        const int el = j + 8 * part;
-                        if (el < 28) {
-                            // raw edge sample for EE8 index e: e<=9: left[9-e] (clamped), 10: corner, >=11: top[e-11]
-                            const int e = min(max(el, 2), 26);
-                            const int maxi = upright ? 15 : 7;
-                            int lo = e - 1, hi = e + 1;
-                            if (e == 2 || (e == 11 && !upleft) || (e == 10 && !left)) lo = e;
-                            if (e == 26 || (e == 9 && !upleft) || (e == 10 && !up)) hi = e;
-                            int v[3];
-                            const int idxs[3] = {lo, e, hi};
-#pragma unroll
-                            for (int t = 0; t < 3; t++) {
-                                const int idx = idxs[t];
-                                v[t] = (idx >= 10) ? (int)Trow[min(idx - 11, maxi)] : (int)Tcol[(9 - idx) * 32];
-                            }
-                            Q.E8[el] = (uint8_t)((v[0] + 2 * v[1] + v[2] + 2) >> 2);
+                    for (int k = 0; k < 7; k++) {
+                        uint32_t Pk = __builtin_amdgcn_alignbyte(Wd[k], Wd[k ? k - 1 : 0], 3);
+                        uint32_t Nk = __builtin_amdgcn_alignbyte(Wd[k < 6 ? k + 1 : 6], Wd[k], 1);
+                        if (k == 2) {
+                            Pk = __builtin_amdgcn_perm(Wd[2], Pk, selP);
+                            Nk = __builtin_amdgcn_perm(Wd[2], Nk, selN);
                         }
+                        Ed[k] = lerp_u8(lerp_u8(Pk, Nk, 0u), Wd[k], 0x01010101u);
+                    }
+                    Ed[0] = __builtin_amdgcn_perm(0u, Ed[0], 0x03020202u);   // entries 0, 1 = p'[-1,7] replicated
+                    Ed[6] = __builtin_amdgcn_perm(0u, Ed[6], 0x02020100u);   // entry 27 = p'[15,-1] replicated
+                    Ed[7] = __builtin_amdgcn_perm(0u, Ed[6], 0x03030303u);
+                    // lane k < 7 publishes words k of the three arrays
+                    {
+                        const bool b0 = (j & 1) != 0, b1 = (j & 2) != 0, b2 = (j & 4) != 0;
+                        const uint32_t a0 = b0 ? Ed[1] : Ed[0], a1 = b0 ? Ed[3] : Ed[2], a2 = b0 ? Ed[5] : Ed[4], a3 = b0 ? Ed[7] : Ed[6];
+                        const uint32_t n0 = b0 ? Ed[2] : Ed[1], n1 = b0 ? Ed[4] : Ed[3], n2 = b0 ? Ed[6] : Ed[5], n3 = Ed[7];
+                        const uint32_t c0 = b1 ? a1 : a0, c1 = b1 ? a3 : a2, d0 = b1 ? n1 : n0, d1 = b1 ? n3 : n2;
+                        const uint32_t Ej = b2 ? c1 : c0, En = b2 ? d1 : d0;
+                        const uint32_t NE = __builtin_amdgcn_alignbyte(En, Ej, 1), N2 = __builtin_amdgcn_alignbyte(En, Ej, 2);
+                        *reinterpret_cast<uint32_t *>(&Q.G[0][j * 4]) = Ej;
+                        *reinterpret_cast<uint32_t *>(&Q.G[1][j * 4]) = lerp_u8(Ej, NE, 0x01010101u);
+                        *reinterpret_cast<uint32_t *>(&Q.G[2][j * 4]) = lerp_u8(lerp_u8(Ej, N2, 0u), NE, 0x01010101u);
                     }
                     WAVE_SYNC();
                     {
                         const int y = j;
-                        uint32_t pwa = 0, pwb = 0;   // samples 0..3 and 4..7 of the row
-                        if (mode == 2) {
-                            const uint32_t *E = reinterpret_cast<const uint32_t *>(Q.E8);
-                            const uint32_t w0 = E[0], w1 = E[1], w2 = E[2], w3 = E[3], w4 = E[4];
-                            const int sumV = sum4(w0 & 0xffff0000u) + sum4(w1) + sum4(w2 & 0x0000ffffu);       // E8[2..9]
-                            const int sumH = sum4(w2 & 0xff000000u) + sum4(w3) + sum4(w4 & 0x00ffffffu);       // E8[11..18]
-                            int v;
-                            if (left && up) v = (sumH + sumV + 8) >> 4;
-                            else if (left) v = (sumV + 4) >> 3;
-                            else if (up) v = (sumH + 4) >> 3;
-                            else v = 128;
-                            pwa = pwb = (uint32_t)v * 0x01010101u;
-                        } else {
-                            bool ok;
-                            switch (mode) {
-                            case 0: case 3: case 7: ok = up; break;
-                            case 1: case 8: ok = left; break;
-                            default: ok = left && up && upleft; break;
-                            }
-                            if (ok && mode < 9) {
-                                const uint4 e4a = *reinterpret_cast<const uint4 *>(&B.tap8[mode * 64 + y * 8]);
-                                const uint4 e4b = *reinterpret_cast<const uint4 *>(&B.tap8[mode * 64 + y * 8 + 4]);
-                                const uint32_t ee[8] = {e4a.x, e4a.y, e4a.z, e4a.w, e4b.x, e4b.y, e4b.z, e4b.w};
-#pragma unroll
-                                for (int x = 0; x < 8; x++) {
-                                    const int v0 = Q.E8[ee[x] & 255], v1 = Q.E8[(ee[x] >> 8) & 255], v2 = Q.E8[ee[x] >> 16];
-                                    const uint32_t pv = (uint32_t)((v0 + 2 * v1 + v2 + 2) >> 2) << (8 * (x & 3));
-                                    if (x < 4) pwa |= pv; else pwb |= pv;
-                                }
-                            }
-                        }
+                        // which neighbours a mode needs (bit 0 left, 1 up, 2 up-left), three bits per mode: the same
+                        // requirements as Intra4x4 (h264_intra_prediction.c:1366-1793 test them mode by mode)
+                        constexpr uint32_t REQ = (2u << 0) | (1u << 3) | (0u << 6) | (2u << 9) | (7u << 12) | (7u << 15) | (7u << 18) |
+                                                 (2u << 21) | (1u << 24);
+                        const uint32_t avail = (left ? 1u : 0u) | (up ? 2u : 0u) | (upleft ? 4u : 0u);
+                        const uint32_t mm = min((uint32_t)mode, 8u);
+                        const bool ok = (((REQ >> (mm * 3u)) & 7u & ~avail) == 0u) && ((uint32_t)mode < 9u);   // else the prediction stays 0
+                        // Intra_8x8_DC (:1435-1500) on the filtered samples: entries 2..9 (left), 11..18 (top)
+                        const int sumV = sum4(Ed[0] & 0xffff0000u) + sum4(Ed[1]) + sum4(Ed[2] & 0x0000ffffu);
+                        const int sumH = sum4(Ed[2] & 0xff000000u) + sum4(Ed[3]) + sum4(Ed[4] & 0x00ffffffu);
+                        int dcv;
+                        if (left && up) dcv = (sumH + sumV + 8) >> 4;
+                        else if (left) dcv = (sumV + 4) >> 3;
+                        else if (up) dcv = (sumH + 4) >> 3;
+                        else dcv = 128;
+                        const uint2 tb = *reinterpret_cast<const uint2 *>(&B.tap8b[mm * 64 + y * 8]);
+                        const uint8_t *Gb = &Q.G[0][0];
+                        const uint32_t s0 = Gb[tb.x & 255u], s1 = Gb[(tb.x >> 8) & 255u], s2 = Gb[(tb.x >> 16) & 255u], s3 = Gb[tb.x >> 24];
+                        const uint32_t s4 = Gb[tb.y & 255u], s5 = Gb[(tb.y >> 8) & 255u], s6 = Gb[(tb.y >> 16) & 255u], s7 = Gb[tb.y >> 24];
+                        const uint32_t dcw = (uint32_t)dcv * 0x01010101u;
+                        const uint32_t okm = ok ? 0xffffffffu : 0u;
+                        const uint32_t pwa = (mode == 2) ? dcw : ((s0 | (s1 << 8) | (s2 << 16) | (s3 << 24)) & okm);   // samples 0..3 of row y
+                        const uint32_t pwb = (mode == 2) ? dcw : ((s4 | (s5 << 8) | (s6 << 16) | (s7 << 24)) & okm);   // samples 4..7
                         int4 rr = make_int4(0, 0, 0, 0);
                         if (need_l) rr = *reinterpret_cast<const int4 *>(&Q.res[blk * 64 + y * 8]);
                         const uint32_t oa = sat_pk_u8(pk_add_sat((int)__builtin_amdgcn_perm(0u, pwa, 0x0c010c00u), rr.x)) |
@@ -676,6 +747,7 @@ MVHP_MARK("p_i8");
                         const uint32_t ob = sat_pk_u8(pk_add_sat((int)__builtin_amdgcn_perm(0u, pwb, 0x0c010c00u), rr.z)) |
                                             (sat_pk_u8(pk_add_sat((int)__builtin_amdgcn_perm(0u, pwb, 0x0c030c02u), rr.w)) << 16);
                         *reinterpret_cast<uint2 *>(&Q.T[(byO + y + 1) * 32 + 16 + bxO]) = make_uint2(oa, ob);
+                        if (bxO == 0) Q.Lc8[y] = (uint8_t)(ob >> 24);   // left neighbours of the block to the right
                     }
                     WAVE_SYNC();
                 }
@@ -683,39 +755,29 @@ MVHP_MARK("p_i8");
             WAVE_SYNC();
 
             // =====================================================================================
-            // write-out (mb_to_rgb, export_utils.c:209-324, fused): lane j holds luma rows j, j+8 and chroma row j of
-            // both planes; park, or flush the 4-macroblock strip
+            // write-out (mb_to_rgb, export_utils.c:209-324, fused): lane j holds luma rows 2j, 2j+1 and chroma row j of both
+            // planes -- the chroma row those two luma rows share (export_utils.c:278-279), so its colour terms are
+            // computed once; park, or flush the 4-macroblock strip
             // =====================================================================================
             MVHP_MARK("writeout");
             {
                 const int mbi = mbx & 3;
-                const uint4 ya = *reinterpret_cast<const uint4 *>(&Q.T[(j + 1) * 32 + 16]);
-                const uint4 yb = *reinterpret_cast<const uint4 *>(&Q.T[(j + 9) * 32 + 16]);
-                const uint2 cvb = *reinterpret_cast<const uint2 *>(&Q.TC[0][(j + 1) * 16 + 8]);
-                const uint2 cvr = *reinterpret_cast<const uint2 *>(&Q.TC[1][(j + 1) * 16 + 8]);
-                uint2 cba = make_uint2(0u, 0u), cra = cba, cbb = cba, crb = cba;   // chroma rows of luma rows j / j+8
-                if (RGB) {
-                    cba = *reinterpret_cast<const uint2 *>(&Q.TC[0][((j >> 1) + 1) * 16 + 8]);
-                    cra = *reinterpret_cast<const uint2 *>(&Q.TC[1][((j >> 1) + 1) * 16 + 8]);
-                    cbb = *reinterpret_cast<const uint2 *>(&Q.TC[0][((j >> 1) + 5) * 16 + 8]);
-                    crb = *reinterpret_cast<const uint2 *>(&Q.TC[1][((j >> 1) + 5) * 16 + 8]);
-                }
+                const uint4 ya = *reinterpret_cast<const uint4 *>(&Q.T[(2 * j + 1) * 32 + 16]);   // luma row 2j
+                const uint4 yb = *reinterpret_cast<const uint4 *>(&Q.T[(2 * j + 2) * 32 + 16]);   // luma row 2j + 1
+                const uint2 cvb = *reinterpret_cast<const uint2 *>(&Q.TC[0][(j + 1) * 16 + 8]);   // chroma row j: the row of
+                const uint2 cvr = *reinterpret_cast<const uint2 *>(&Q.TC[1][(j + 1) * 16 + 8]);   // both luma rows
                 const v4i yqa = {(int)ya.x, (int)ya.y, (int)ya.z, (int)ya.w}, yqb = {(int)yb.x, (int)yb.y, (int)yb.z, (int)yb.w};
                 n_st = 0;
                 if (mbi == 3 || mbx == W - 1) {
                     uint32_t qmb_v = qmb;
                     asm volatile("" : "+v"(qmb_v));
                     const uint32_t oyuv = OYUV;
-                    const uint32_t lrow = (uint32_t)((row * 16 + j) * pitch + (mbx & ~3) * 16);   // luma row j, inside the plane
-                    const uint32_t pya = oyuv + lrow, pyb = pya + 8 * pitch;
+                    const uint32_t lrow = (uint32_t)((row * 16 + 2 * j) * pitch + (mbx & ~3) * 16);   // luma row 2j, inside the plane
+                    const uint32_t pya = oyuv + lrow, pyb = pya + pitch;
                     const uint32_t pcb = oyuv + plane_y + (uint32_t)((row * 8 + j) * cpitch + (mbx & ~3) * 8), pcr = pcb + plane_c;
-                    const uint32_t prgba = ORGB + lrow * 3u, prgbb = prgba + 24 * pitch;
+                    const uint32_t prgba = ORGB + lrow * 3u, prgbb = prgba + 3 * pitch;
                     const uint2 *ownb = reinterpret_cast<const uint2 *>(&Q.SC[0][j * 24]);   // parked: this lane's chroma rows
                     const uint2 *ownr = reinterpret_cast<const uint2 *>(&Q.SC[1][j * 24]);
-                    const uint2 *pba = reinterpret_cast<const uint2 *>(&Q.SC[0][(j >> 1) * 24]);        // parked: rows for RGB
-                    const uint2 *pra = reinterpret_cast<const uint2 *>(&Q.SC[1][(j >> 1) * 24]);
-                    const uint2 *pbb = reinterpret_cast<const uint2 *>(&Q.SC[0][((j >> 1) + 4) * 24]);
-                    const uint2 *prb = reinterpret_cast<const uint2 *>(&Q.SC[1][((j >> 1) + 4) * 24]);
 MVHP_MARK("w_full");
                     if (mbi == 3) {
                         // ---- full strip: exactly VM_STRIP store instructions ----
@@ -739,46 +801,40 @@ MVHP_MARK("w_full");
 #else
 #define MVHP_RGB_STORE_COND valid
 #endif
-#define MVHP_RGB_OUT(ADDR, YQ, CB, CR, OFF)                                                                            \
+                            // one macroblock of the strip: both luma rows against the chroma row they share
+#define MVHP_RGB_OUT(YQA, YQB, CB, CR, OFF)                                                                            \
                             {                                                                                          \
-                                v4i a0, a1, a2;                                                                        \
-                                const uint4 yy = make_uint4((uint32_t)(YQ).x, (uint32_t)(YQ).y, (uint32_t)(YQ).z, (uint32_t)(YQ).w); \
-                                rgb16(yy, CB, CR, a0, a1, a2);                                                         \
+                                v4i a0, a1, a2, c0, c1, c2;                                                            \
+                                rgb16x2(make_uint4((uint32_t)(YQA).x, (uint32_t)(YQA).y, (uint32_t)(YQA).z, (uint32_t)(YQA).w), \
+                                        make_uint4((uint32_t)(YQB).x, (uint32_t)(YQB).y, (uint32_t)(YQB).z, (uint32_t)(YQB).w), \
+                                        CB, CR, a0, a1, a2, c0, c1, c2);                                               \
                                 if (MVHP_RGB_STORE_COND) {                                                             \
-                                    MVHP_ST(ADDR, a0, grgb, OFF); MVHP_ST(ADDR, a1, grgb, OFF + 16); MVHP_ST(ADDR, a2, grgb, OFF + 32); \
+                                    MVHP_ST(prgba, a0, grgb, OFF); MVHP_ST(prgba, a1, grgb, OFF + 16); MVHP_ST(prgba, a2, grgb, OFF + 32); \
+                                    MVHP_ST(prgbb, c0, grgb, OFF); MVHP_ST(prgbb, c1, grgb, OFF + 16); MVHP_ST(prgbb, c2, grgb, OFF + 32); \
                                 } else {                                                                               \
-                                    asm volatile("" : : "v"(a0), "v"(a1), "v"(a2));                                    \
+                                    asm volatile("" : : "v"(a0), "v"(a1), "v"(a2), "v"(c0), "v"(c1), "v"(c2));         \
                                 }                                                                                      \
                             }
-                            MVHP_RGB_OUT(prgba, st_a0, pba[0], pra[0], 0)
-                            MVHP_RGB_OUT(prgba, st_a1, pba[1], pra[1], 48)
-                            MVHP_RGB_OUT(prgba, st_a2, pba[2], pra[2], 96)
-                            MVHP_RGB_OUT(prgba, yqa, cba, cra, 144)
-                            MVHP_RGB_OUT(prgbb, st_b0, pbb[0], prb[0], 0)
-                            MVHP_RGB_OUT(prgbb, st_b1, pbb[1], prb[1], 48)
-                            MVHP_RGB_OUT(prgbb, st_b2, pbb[2], prb[2], 96)
-                            MVHP_RGB_OUT(prgbb, yqb, cbb, crb, 144)
+                            MVHP_RGB_OUT(st_a0, st_b0, b0, q0, 0)
+                            MVHP_RGB_OUT(st_a1, st_b1, b1, q1, 48)
+                            MVHP_RGB_OUT(st_a2, st_b2, b2, q2, 96)
+                            MVHP_RGB_OUT(yqa, yqb, cvb, cvr, 144)
 #undef MVHP_RGB_OUT
 #undef MVHP_RGB_STORE_COND
                         }
 #undef MVHP_ST
                         n_st = VM_STRIP;
                     } else {
-MVHP_MARK("w_short");
                         // ---- short strip at the right picture edge (W % 4 != 0): compiler-counted stores ----
 #pragma unroll
                         for (int k = 0; k < 3; k++) {
                             if (k > mbi) continue;
                             const bool last = (k == mbi);
                             const v4i yka = last ? yqa : (k == 0 ? st_a0 : st_a1), ykb = last ? yqb : (k == 0 ? st_b0 : st_b1);
-                            const uint2 ob = ownb[k], orr = ownr[k], xba = pba[k], xra = pra[k], xbb = pbb[k], xrb = prb[k];   // read first, then choose values
-                            uint2 ckb, ckr, kba, kra, kbb, krb;
+                            const uint2 ob = ownb[k], orr = ownr[k];   // read first, then choose values
+                            uint2 ckb, ckr;
                             ckb.x = last ? cvb.x : ob.x; ckb.y = last ? cvb.y : ob.y;
                             ckr.x = last ? cvr.x : orr.x; ckr.y = last ? cvr.y : orr.y;
-                            kba.x = last ? cba.x : xba.x; kba.y = last ? cba.y : xba.y;
-                            kra.x = last ? cra.x : xra.x; kra.y = last ? cra.y : xra.y;
-                            kbb.x = last ? cbb.x : xbb.x; kbb.y = last ? cbb.y : xbb.y;
-                            krb.x = last ? crb.x : xrb.x; krb.y = last ? crb.y : xrb.y;
                             if (valid) {
                                 *reinterpret_cast<v4i *>(gyuv + pya + k * 16) = yka;
                                 *reinterpret_cast<v4i *>(gyuv + pyb + k * 16) = ykb;
@@ -786,16 +842,14 @@ MVHP_MARK("w_short");
                                 *reinterpret_cast<uint2 *>(gyuv + pcr + k * 8) = ckr;
                             }
                             if (RGB) {
-                                v4i a0, a1, a2;
-                                rgb16(make_uint4((uint32_t)yka.x, (uint32_t)yka.y, (uint32_t)yka.z, (uint32_t)yka.w), kba, kra, a0, a1, a2);
+                                v4i a0, a1, a2, c0, c1, c2;
+                                rgb16x2(make_uint4((uint32_t)yka.x, (uint32_t)yka.y, (uint32_t)yka.z, (uint32_t)yka.w),
+                                        make_uint4((uint32_t)ykb.x, (uint32_t)ykb.y, (uint32_t)ykb.z, (uint32_t)ykb.w), ckb, ckr, a0, a1, a2, c0, c1, c2);
                                 if (valid) {
                                     v4i *dst = reinterpret_cast<v4i *>(grgb + prgba + k * 48);
                                     dst[0] = a0; dst[1] = a1; dst[2] = a2;
-                                }
-                                rgb16(make_uint4((uint32_t)ykb.x, (uint32_t)ykb.y, (uint32_t)ykb.z, (uint32_t)ykb.w), kbb, krb, a0, a1, a2);
-                                if (valid) {
-                                    v4i *dst = reinterpret_cast<v4i *>(grgb + prgbb + k * 48);
-                                    dst[0] = a0; dst[1] = a1; dst[2] = a2;
+                                    dst = reinterpret_cast<v4i *>(grgb + prgbb + k * 48);
+                                    dst[0] = c0; dst[1] = c1; dst[2] = c2;
                                 }
                             }
                         }
@@ -859,7 +913,7 @@ MVHP_MARK("w_park");
 
 size_t recon_oct_lds_bytes(int width_mbs, int nw)
 {
-    return sizeof(QTables) + (size_t)8 * width_mbs * 32 + (size_t)nw * 8 * sizeof(QLds);
+    return sizeof(OTables) + (size_t)8 * width_mbs * 32 + (size_t)nw * 8 * sizeof(OLds);
 }
 
 template <int NW, bool RGB>
