@@ -81,7 +81,6 @@ public:
         return pos_ < last;
     }
 
-private:
     // the bits from the current position on, left-aligned (at least 57 of them valid)
     uint64_t window() const
     {
@@ -97,9 +96,35 @@ private:
         return w << (pos_ & 7);
     }
 
+private:
     const uint8_t *p_;
     size_t n_bytes_, n_bits_;
     size_t pos_;
+};
+
+// A local view for hot loops: the 64-bit window is fetched once and consumed from a register; it is fetched again only
+// when a read would run past its 57 valid bits.  The reader's position is brought up to date when the view ends.
+class BitWindow {
+public:
+    explicit BitWindow(BitReader &br) : br_(br), w_(br.window()), used_(0) {}
+    ~BitWindow() { br_.skip((size_t)used_); }
+    BitWindow(const BitWindow &) = delete;
+    BitWindow &operator=(const BitWindow &) = delete;
+    uint32_t peek(int n)   // n <= 32
+    {
+        if (used_ + n > 57) { br_.skip((size_t)used_); w_ = br_.window(); used_ = 0; }
+        return n ? (uint32_t)((w_ << used_) >> (64 - n)) : 0u;
+    }
+    void skip(int n) { used_ += n; }   // (behind a peek of at least n bits, or up to 32 bits further)
+    uint32_t bits(int n) { const uint32_t v = peek(n); used_ += n; return v; }
+    uint32_t bit() { return bits(1); }
+    int leading_zeros32() { const uint32_t v = peek(32); return v ? __builtin_clz(v) : 32; }
+    bool overrun() const { return br_.pos() + (size_t)used_ > br_.size_bits(); }
+
+private:
+    BitReader &br_;
+    uint64_t w_;
+    int used_;
 };
 
 } // namespace h264

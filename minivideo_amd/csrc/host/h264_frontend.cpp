@@ -297,8 +297,12 @@ int PictureDecoder::slice_data(std::string &err)
         cabac_ = new CabacEngine(*this);
         cabac_->init(slice_qp_);
     }
+    cur_x_ = 0;
     for (int addr = 0; addr < n_mbs; addr++) {
+        cur_addr_ = addr;
+        curA_ = cur_x_ > 0 ? addr - 1 : -1;
         int rc = macroblock(addr, err);
+        if (++cur_x_ == W_) cur_x_ = 0;
         if (rc != RC_SUCCESS) return rc;
         if (pps_.entropy_coding_mode) {
             const int end = cabac_->decode_terminate();
@@ -312,33 +316,44 @@ int PictureDecoder::slice_data(std::string &err)
     return RC_SUCCESS;
 }
 
-// neighbouring 4x4 luma blocks (6.4.11.4 via h264_spatial.c:559): returns MB address or -1
-static inline int luma_neighbour_A(int addr, int W, int blk, int *blkN)
+// neighbouring 4x4 blocks (6.4.11.4 via h264_spatial.c:559 luma, :631 chroma): inside the macroblock or in A / B
+namespace {
+struct NeighbourTables {
+    uint8_t lumaA[16], lumaB[16];      // bit 7: the neighbour lies in macroblock A (B); low bits: its block index
+    NeighbourTables()
+    {
+        for (int blk = 0; blk < 16; blk++) {
+            const int x = blk4_x(blk), y = blk4_y(blk);
+            lumaA[blk] = (uint8_t)(x > 0 ? blk4_from_xy(x - 4, y) : (0x80 | blk4_from_xy(12, y)));
+            lumaB[blk] = (uint8_t)(y > 0 ? blk4_from_xy(x, y - 4) : (0x80 | blk4_from_xy(x, 12)));
+        }
+    }
+};
+const NeighbourTables g_nb;
+} // namespace
+static inline int luma_neighbour_A(int addr, int addrA, int blk, int *blkN)
 {
-    const int x = blk4_x(blk), y = blk4_y(blk);
-    if (x > 0) { *blkN = blk4_from_xy(x - 4, y); return addr; }
-    *blkN = blk4_from_xy(12, y);
-    return (addr % W) > 0 ? addr - 1 : -1;
+    const uint8_t e = g_nb.lumaA[blk];
+    *blkN = e & 15;
+    return (e & 0x80) ? addrA : addr;
 }
-static inline int luma_neighbour_B(int addr, int W, int blk, int *blkN)
+static inline int luma_neighbour_B(int addr, int addrB, int blk, int *blkN)
 {
-    const int x = blk4_x(blk), y = blk4_y(blk);
-    if (y > 0) { *blkN = blk4_from_xy(x, y - 4); return addr; }
-    *blkN = blk4_from_xy(x, 12);
-    return addr >= W ? addr - W : -1;
+    const uint8_t e = g_nb.lumaB[blk];
+    *blkN = e & 15;
+    return (e & 0x80) ? addrB : addr;
 }
-// neighbouring 4x4 chroma blocks, 4:2:0 (h264_spatial.c:631)
-static inline int chroma_neighbour_A(int addr, int W, int blk, int *blkN)
+static inline int chroma_neighbour_A(int addr, int addrA, int blk, int *blkN)
 {
     if (blk & 1) { *blkN = blk - 1; return addr; }
     *blkN = blk + 1;
-    return (addr % W) > 0 ? addr - 1 : -1;
+    return addrA;
 }
-static inline int chroma_neighbour_B(int addr, int W, int blk, int *blkN)
+static inline int chroma_neighbour_B(int addr, int addrB, int blk, int *blkN)
 {
     if (blk & 2) { *blkN = blk - 2; return addr; }
     *blkN = blk + 2;
-    return addr >= W ? addr - W : -1;
+    return addrB;
 }
 
 // G1: Intra_4x4_deriv_PredMode (h264_intra_prediction.c:196-290) and
@@ -349,7 +364,7 @@ void PictureDecoder::derive_pred_modes(int addr, const uint8_t prev_flag[16], co
     if (mb.kind == MVHP_KIND_I4x4) {
         for (int blk = 0; blk < 16; blk++) {
             int bA, bB;
-            const int aA = luma_neighbour_A(addr, W_, blk, &bA), aB = luma_neighbour_B(addr, W_, blk, &bB);
+            const int aA = luma_neighbour_A(addr, mbA(addr), blk, &bA), aB = luma_neighbour_B(addr, mbB(addr), blk, &bB);
             int mA = 2, mB = 2;
             if (aA >= 0 && aB >= 0) {
                 const MbState &A = mbs_[aA], &B = mbs_[aB];
@@ -583,13 +598,13 @@ int PictureDecoder::nC_for(int addr, int cat, int blkIdx) const
     int aA, aB, bA = 0, bB = 0, nA = 0, nB = 0;
     if (cat == CAT_CHROMA_AC_CB || cat == CAT_CHROMA_AC_CR) {
         const int c = cat - CAT_CHROMA_AC_CB;
-        aA = chroma_neighbour_A(addr, W_, blkIdx, &bA);
-        aB = chroma_neighbour_B(addr, W_, blkIdx, &bB);
+        aA = chroma_neighbour_A(addr, mbA(addr), blkIdx, &bA);
+        aB = chroma_neighbour_B(addr, mbB(addr), blkIdx, &bB);
         if (aA >= 0) nA = mbs_[aA].tc_c[c][bA];
         if (aB >= 0) nB = mbs_[aB].tc_c[c][bB];
     } else {
-        aA = luma_neighbour_A(addr, W_, blkIdx, &bA);
-        aB = luma_neighbour_B(addr, W_, blkIdx, &bB);
+        aA = luma_neighbour_A(addr, mbA(addr), blkIdx, &bA);
+        aB = luma_neighbour_B(addr, mbB(addr), blkIdx, &bB);
         if (aA >= 0) nA = mbs_[aA].tc_luma[bA];
         if (aB >= 0) nB = mbs_[aB].tc_luma[bB];
     }
@@ -659,21 +674,22 @@ int PictureDecoder::residual_block_cavlc(int addr, int startIdx, int endIdx, int
 {
     MbState &mb = mbs_[addr];
     const int nC = nC_for(addr, cat, blkIdx);
+    BitWindow bw(br_);   // (the member reader is not used below: its position is updated when bw ends)
     int total = -1, t1s = 0;
     // 9.2.1 coeff_token
     if (nC >= 8) {
-        const unsigned v = br_.bits(6);
+        const unsigned v = bw.bits(6);
         if (v == 3) { total = 0; t1s = 0; }
         else { total = (int)(v >> 2) + 1; t1s = (int)(v & 3); if (t1s > total) return RC_FAILURE; }
     } else if (nC == -1) {
-        const uint16_t e = g_cavlc.coeff_token_cdc[br_.peek(8)];
-        if (e) { br_.skip(e & 15u); total = (e >> 4) & 15; t1s = e >> 8; }
+        const uint16_t e = g_cavlc.coeff_token_cdc[bw.peek(8)];
+        if (e) { bw.skip((int)(e & 15u)); total = (e >> 4) & 15; t1s = e >> 8; }
     } else {
         const int tab = nC < 2 ? 0 : (nC < 4 ? 1 : 2);
-        const int lz = br_.leading_zeros32();
+        const int lz = bw.leading_zeros32();
         if (lz <= 16) {
-            const uint32_t e = g_cavlc.coeff_token[tab][lz][(br_.peek(lz + 4) & 7u)];
-            if (e) { br_.skip(e & 255u); total = (int)((e >> 8) & 255u); t1s = (int)(e >> 16); }
+            const uint32_t e = g_cavlc.coeff_token[tab][lz][(bw.peek(lz + 4) & 7u)];
+            if (e) { bw.skip((int)(e & 255u)); total = (int)((e >> 8) & 255u); t1s = (int)(e >> 16); }
         }
     }
     if (total < 0) return RC_FAILURE;
@@ -689,17 +705,17 @@ int PictureDecoder::residual_block_cavlc(int addr, int startIdx, int endIdx, int
     int suffixLength = (total > 10 && t1s < 3) ? 1 : 0;
     for (int i = 0; i < total; i++) {
         if (i < t1s) {
-            level[i] = 1 - 2 * (int)br_.bit();
+            level[i] = 1 - 2 * (int)bw.bit();
         } else {
-            const int level_prefix = br_.leading_zeros32();
-            if (level_prefix > 28 || br_.overrun()) return RC_FAILURE;
-            br_.skip((size_t)level_prefix + 1);
+            const int level_prefix = bw.leading_zeros32();
+            if (level_prefix > 28 || bw.overrun()) return RC_FAILURE;
+            bw.skip(level_prefix + 1);
             int levelCode = (level_prefix < 15 ? level_prefix : 15) << suffixLength;
             if (suffixLength > 0 || level_prefix >= 14) {
                 int size = suffixLength;
                 if (level_prefix == 14 && suffixLength == 0) size = 4;
                 else if (level_prefix > 14) size = level_prefix - 3;
-                if (size > 0) levelCode += (int)br_.bits(size);
+                if (size > 0) levelCode += (int)bw.bits(size);
             }
             if (level_prefix >= 15 && suffixLength == 0) levelCode += 15;
             if (level_prefix >= 16) levelCode += (1 << (level_prefix - 3)) - 4096;
@@ -713,14 +729,14 @@ int PictureDecoder::residual_block_cavlc(int addr, int startIdx, int endIdx, int
     if (total < endIdx - startIdx + 1) {
         int tz;
         if (cat == CAT_CHROMA_DC_CB || cat == CAT_CHROMA_DC_CR) {
-            const uint8_t e = g_cavlc.total_zeros_cdc[total - 1][br_.peek(3)];
+            const uint8_t e = g_cavlc.total_zeros_cdc[total - 1][bw.peek(3)];
             if (!e) return RC_FAILURE;
-            br_.skip(e & 15u);
+            bw.skip((int)(e & 15u));
             tz = e >> 4;
         } else {
-            const uint16_t e = g_cavlc.total_zeros[total - 1][br_.peek(9)];
+            const uint16_t e = g_cavlc.total_zeros[total - 1][bw.peek(9)];
             if (!e) return RC_FAILURE;
-            br_.skip(e & 255u);
+            bw.skip((int)(e & 255u));
             tz = e >> 8;
         }
         zerosLeft = tz;
@@ -729,17 +745,17 @@ int PictureDecoder::residual_block_cavlc(int addr, int startIdx, int endIdx, int
         if (zerosLeft > 0) {
             int rb;
             if (zerosLeft <= 6) {
-                const uint8_t e = g_cavlc.run_before[zerosLeft - 1][br_.peek(3)];
+                const uint8_t e = g_cavlc.run_before[zerosLeft - 1][bw.peek(3)];
                 if (!e) return RC_FAILURE;
-                br_.skip(e & 15u);
+                bw.skip((int)(e & 15u));
                 rb = e >> 4;
             } else { // Table 9-10, zerosLeft > 6: 3-bit codes 111..001 = 0..6, then 0001 = 7, 00001 = 8, ...
-                const uint32_t v3 = br_.peek(3);
-                if (v3) { br_.skip(3); rb = 7 - (int)v3; }
+                const uint32_t v3 = bw.peek(3);
+                if (v3) { bw.skip(3); rb = 7 - (int)v3; }
                 else {
-                    const int lz = br_.leading_zeros32();
+                    const int lz = bw.leading_zeros32();
                     if (lz > 10) return RC_FAILURE;
-                    br_.skip((size_t)lz + 1);
+                    bw.skip(lz + 1);
                     rb = lz + 4;
                 }
             }

@@ -127,8 +127,8 @@ private:
         nz_cur_ |= sink_.nz_per_coef ? (sink_.nz_bit << slot) : sink_.nz_bit;
     }
 
-    // neighbour helpers: address of MB A/B or -1
-    int mbA(int addr) const { return (addr % W_) > 0 ? addr - 1 : -1; }
+    // neighbour helpers: address of MB A/B or -1 (cached for the macroblock being parsed: no division per call)
+    int mbA(int addr) const { return addr == cur_addr_ ? curA_ : ((addr % W_) > 0 ? addr - 1 : -1); }
     int mbB(int addr) const { return addr >= W_ ? addr - W_ : -1; }
 
     const Sps &sps_;
@@ -142,6 +142,7 @@ private:
     CabacEngine *cabac_ = nullptr;
     bool       level_overflow_ = false;
     Sink       sink_;
+    int        cur_addr_ = -1, curA_ = -1, cur_x_ = 0;   // the macroblock being parsed, its left neighbour, its column
     uint32_t   nz_cur_ = 0;      // nz_mask of the macroblock being decoded
 };
 

@@ -71,3 +71,27 @@ def test_shard_is_balanced_partition():
             assert all(cuts[i][1] == cuts[i + 1][0] for i in range(w - 1))
             sizes = [b - a for a, b in cuts]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_bench_refuses_a_rank_count_that_does_not_match():
+    """`bench.py --gpus 8` must never run on one GPU and print n_gpus: 1.  Started bare it launches the ranks
+    itself (and fails when the devices are not there); under a launcher, --gpus and WORLD_SIZE must agree."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True,
+                       timeout=300, env=env)
+    assert r.returncode != 0 and "HIP device" in (r.stderr + r.stdout)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True,
+                       timeout=300, env=dict(env, WORLD_SIZE="4", RANK="0"))
+    assert r.returncode != 0 and "does not match WORLD_SIZE=4" in (r.stderr + r.stdout)
+    assert '"n_gpus"' not in r.stdout
+
+
+def test_strong_scaling_shares_cover_the_batch():
+    """--strong P: the ranks' shares are contiguous, disjoint and add up to P (config 5: 512 pictures over 8 GPUs)."""
+    from minivideo_amd.dist import shard
+    for P, world in ((512, 8), (512, 3), (7, 8), (2048, 5)):
+        cuts = [shard(P, r, world) for r in range(world)]
+        assert cuts[0][0] == 0 and cuts[-1][1] == P
+        assert all(cuts[i][1] == cuts[i + 1][0] for i in range(world - 1))
+        assert max(hi - lo for lo, hi in cuts) - min(hi - lo for lo, hi in cuts) <= 1
