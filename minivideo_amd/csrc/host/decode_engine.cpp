@@ -278,8 +278,10 @@ int Engine::chunk_pictures(const mvhp_stream_params_t &p) const
 }
 
 // pictures per launch.  Speed only: the batch kernels want >= 3 x CUs (four pictures per workgroup) or >= 8 x CUs
-// (eight) pictures; the host entropy stage is the slower side by far, so a batch is at most what one context's share
-// of the remaining pictures is, and never more than the device memory budget holds.
+// (eight) pictures, but the host entropy stage is the slower side by far, so what matters is the END of a job: the last
+// batch's kernel and download are not hidden behind any entropy work.  Batches therefore taper -- each takes at most half
+// of what is left per context, down to 64 pictures (1024, 512, 256, 128, 64, 64 for 2048 pictures: the exposed tail is the
+// download of 64 pictures instead of 1024) -- never more than one context's share, the cap, or the device memory budget.
 int Engine::batch_capacity(const mvhp_stream_params_t &p, int remaining) const
 {
     const int n_ctx = (int)ctx_.size();
@@ -290,7 +292,8 @@ int Engine::batch_capacity(const mvhp_stream_params_t &p, int remaining) const
     const int mem_cap = (int)std::min<size_t>(1 << 20, std::max<size_t>(1, budget / std::max<size_t>(1, per_pic)));
     cap = std::min(cap, mem_cap);
     const int share = (remaining + n_ctx - 1) / n_ctx;
-    return std::max(1, std::min(cap, share));
+    const int taper = opts_.batch_pictures > 0 ? cap : std::max(64, (remaining + 2 * n_ctx - 1) / (2 * n_ctx));   // (an explicit batch size is taken as given)
+    return std::max(1, std::min(cap, std::min(share, taper)));
 }
 
 bool Engine::ensure_devbuf(Ctx &c, DevBuf &b, const Batch &bt, std::string &err)

@@ -164,12 +164,9 @@ int CabacEngine::cbf_ctx_inc(int addr, int cat, int blkIdx) const
         condA = mb_cond(a, 16, a >= 0 && pd_.mbs_[a].kind == MVHP_KIND_I16x16);
         condB = mb_cond(b, 16, b >= 0 && pd_.mbs_[b].kind == MVHP_KIND_I16x16);
     } else if (cat == CAT_LUMA_4x4 || cat == CAT_LUMA_16x16_AC) {
-        int bA = 0, bB = 0, a, b;
-        {
-            const int x = blk4_x(blkIdx), y = blk4_y(blkIdx);
-            if (x > 0) { a = addr; bA = blk4_from_xy(x - 4, y); } else { a = pd_.mbA(addr); bA = blk4_from_xy(12, y); }
-            if (y > 0) { b = addr; bB = blk4_from_xy(x, y - 4); } else { b = pd_.mbB(addr); bB = blk4_from_xy(x, 12); }
-        }
+        const uint8_t eA = nb_tables().lumaA[blkIdx], eB = nb_tables().lumaB[blkIdx];
+        const int bA = eA & 15, bB = eB & 15;
+        const int a = (eA & 0x80) ? pd_.mbA(addr) : addr, b = (eB & 0x80) ? pd_.mbB(addr) : addr;
         (void)W;
         condA = mb_cond(a, bA, a >= 0 && ((pd_.mbs_[a].cbp_luma >> (bA >> 2)) & 1));
         condB = mb_cond(b, bB, b >= 0 && ((pd_.mbs_[b].cbp_luma >> (bB >> 2)) & 1));
@@ -218,28 +215,47 @@ int CabacEngine::residual_block(int addr, int startIdx, int endIdx, int maxNumCo
     const int sig_base = is8 ? 402 : 105 + kSigOff[cat];
     const int last_base = is8 ? 417 : 166 + kSigOff[cat];
     const int abs_base = is8 ? 426 : 227 + kAbsOff[cat];
-    uint8_t sig[64];
-    memset(sig, 0, sizeof(sig));
+    // significance map as a bit mask (bit i = coefficient i is significant), levels in reverse scan order (:236-316)
+    uint64_t sigmask = 0;
     int numCoeff = endIdx + 1;
+    if (numCoeff > 64) return RC_FAILURE;
     int i = startIdx;
-    while (i < numCoeff - 1) {
-        const int inc_s = is8 ? kSigInc8x8[i] : (cdc ? (i < 2 ? i : 2) : i);
-        sig[i] = (uint8_t)decode_decision(sig_base + inc_s);
-        if (sig[i]) {
-            const int inc_l = is8 ? kLastInc8x8[i] : (cdc ? (i < 2 ? i : 2) : i);
-            if (decode_decision(last_base + inc_l)) numCoeff = i + 1;
+    if (is8) {
+        while (i < numCoeff - 1) {
+            if (decode_decision(sig_base + kSigInc8x8[i])) {
+                sigmask |= 1ull << i;
+                if (decode_decision(last_base + kLastInc8x8[i])) numCoeff = i + 1;
+            }
+            i++;
         }
-        i++;
+    } else if (cdc) {
+        while (i < numCoeff - 1) {
+            const int inc = i < 2 ? i : 2;
+            if (decode_decision(sig_base + inc)) {
+                sigmask |= 1ull << i;
+                if (decode_decision(last_base + inc)) numCoeff = i + 1;
+            }
+            i++;
+        }
+    } else {
+        while (i < numCoeff - 1) {
+            if (decode_decision(sig_base + i)) {
+                sigmask |= 1ull << i;
+                if (decode_decision(last_base + i)) numCoeff = i + 1;
+            }
+            i++;
+        }
     }
-    sig[numCoeff - 1] = 1;
+    sigmask |= 1ull << (numCoeff - 1);
     int eq1 = 0, gt1 = 0;
-    for (i = numCoeff - 1; i >= startIdx; i--) {
-        if (!sig[i]) continue;
+    const int lim = 4 - (cdc ? 1 : 0);
+    while (sigmask) {
+        i = 63 - __builtin_clzll(sigmask);
+        sigmask &= ~(1ull << i);
         // coeff_abs_level_minus1: UEG0, signedValFlag=0, uCoff=14 (9.3.2.3)
         const int inc0 = (gt1 != 0) ? 0 : ((1 + eq1) < 4 ? (1 + eq1) : 4);
         int v = 0;
         if (decode_decision(abs_base + inc0)) {
-            const int lim = 4 - (cdc ? 1 : 0);
             const int incn = 5 + (gt1 < lim ? gt1 : lim);
             v = 1;
             while (v < 14 && decode_decision(abs_base + incn)) v++;
@@ -255,7 +271,6 @@ int CabacEngine::residual_block(int addr, int startIdx, int endIdx, int maxNumCo
         const int sign = decode_bypass();
         const int lvl = v + 1;
         if (lvl == 1) eq1++; else gt1++;
-        if (i >= 64) return RC_FAILURE;
         pd_.put(i, sign ? -lvl : lvl);
     }
     (void)maxNumCoeff;

@@ -317,29 +317,15 @@ int PictureDecoder::slice_data(std::string &err)
 }
 
 // neighbouring 4x4 blocks (6.4.11.4 via h264_spatial.c:559 luma, :631 chroma): inside the macroblock or in A / B
-namespace {
-struct NeighbourTables {
-    uint8_t lumaA[16], lumaB[16];      // bit 7: the neighbour lies in macroblock A (B); low bits: its block index
-    NeighbourTables()
-    {
-        for (int blk = 0; blk < 16; blk++) {
-            const int x = blk4_x(blk), y = blk4_y(blk);
-            lumaA[blk] = (uint8_t)(x > 0 ? blk4_from_xy(x - 4, y) : (0x80 | blk4_from_xy(12, y)));
-            lumaB[blk] = (uint8_t)(y > 0 ? blk4_from_xy(x, y - 4) : (0x80 | blk4_from_xy(x, 12)));
-        }
-    }
-};
-const NeighbourTables g_nb;
-} // namespace
 static inline int luma_neighbour_A(int addr, int addrA, int blk, int *blkN)
 {
-    const uint8_t e = g_nb.lumaA[blk];
+    const uint8_t e = nb_tables().lumaA[blk];
     *blkN = e & 15;
     return (e & 0x80) ? addrA : addr;
 }
 static inline int luma_neighbour_B(int addr, int addrB, int blk, int *blkN)
 {
-    const uint8_t e = g_nb.lumaB[blk];
+    const uint8_t e = nb_tables().lumaB[blk];
     *blkN = e & 15;
     return (e & 0x80) ? addrB : addr;
 }

@@ -101,4 +101,20 @@ static inline int blk4_y(int b) { return ((b >> 3) << 3) | (((b >> 1) & 1) << 2)
 // sample offsets (multiples of 4) -> luma4x4BlkIdx
 static inline int blk4_from_xy(int x, int y) { return ((y >> 3) << 3) | ((x >> 3) << 2) | (((y >> 2) & 1) << 1) | ((x >> 2) & 1); }
 
+// neighbouring 4x4 luma blocks (6.4.11.4 via h264_spatial.c:559) as tables: bit 7 = the neighbour lies in macroblock
+// A (left) / B (above), low bits = its luma4x4BlkIdx
+struct NeighbourTables {
+    uint8_t lumaA[16], lumaB[16];
+    NeighbourTables()
+    {
+        for (int blk = 0; blk < 16; blk++) {
+            const int x = blk4_x(blk), y = blk4_y(blk);
+            lumaA[blk] = (uint8_t)(x > 0 ? blk4_from_xy(x - 4, y) : (0x80 | blk4_from_xy(12, y)));
+            lumaB[blk] = (uint8_t)(y > 0 ? blk4_from_xy(x, y - 4) : (0x80 | blk4_from_xy(x, 12)));
+        }
+    }
+};
+static const NeighbourTables g_nb_tables;   // (one copy per translation unit: no initialisation guard on the hot path)
+static inline const NeighbourTables &nb_tables() { return g_nb_tables; }
+
 } // namespace h264

@@ -25,7 +25,7 @@ cd $W
 t0=$(date +%s.%N)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_${TAG}_api -- $R/minivideo_amd/mini_thumbnailer -i $W/clip.264 -f yuv420 -n $N > $OUT/${TAG}_api.log 2>&1
 t1=$(date +%s.%N)
-echo "pictures $N files $(ls $W | grep -c yuv) wall_with_profiler_s $(echo "$t1 - $t0" | bc)" >> $OUT/${TAG}_api.log
+echo "pictures $N files $(ls $W | grep -c yuv) wall_with_profiler_s $(python3 -c "print($t1 - $t0)")" >> $OUT/${TAG}_api.log
 f=$(find $OUT/prof_${TAG}_api -name '*kernel_stats.csv' | head -1)
 cp "$f" $OUT/${TAG}_api_kernel_stats.csv
 grep -E "recon_|decode:" $OUT/${TAG}_api_kernel_stats.csv $OUT/${TAG}_api.log | cut -c1-200
