@@ -239,7 +239,7 @@ def end_to_end(args, params, stream, n_distinct, rec, want_rgb, total, rank, wor
     torch.cuda.synchronize(dev)
     wall = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([wall], dtype=torch.float64, device=dev)
+        t = torch.tensor([wall], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = float(t.item())
     eng.close()
@@ -293,6 +293,11 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # rehearsal on a one-GPU box (never a result): every rank on device 0, control plane over gloo -- exercises the
+    # sharding, the per-rank end-to-end leg and the rank-0 line without a second GPU
+    rehearsal = os.environ.get("BENCH_REHEARSE_ON_ONE_GPU") == "1"
+    if rehearsal:
+        local_rank = 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -300,7 +305,10 @@ def main():
         raise SystemExit("bench.py needs a HIP device: the reconstruction hot path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     from minivideo_amd import HotPath
     from minivideo_amd.dist import shard
@@ -397,7 +405,7 @@ def main():
     recon_name = {"rows": "recon_rows_kernel", "quad": "recon_quad_kernel", "oct": "recon_oct_kernel"}[layout_name]
 
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -461,6 +469,7 @@ def main():
             "scaling": "strong" if args.strong else "weak",
             "vs_baseline": None,
             "dtype": "int32",
+            "rehearsal_all_ranks_on_one_gpu": True if rehearsal else None,
             "data": (f"synthetic ({n_distinct} distinct {args.density} pictures of a generated "
                      f"{'CAVLC' if args.profile == 'baseline' else 'CABAC'} Annex-B stream, entropy-decoded by the host front end, "
                      if args.source == "stream" else f"synthetic ({n_distinct} distinct random {args.density} pictures, ")
