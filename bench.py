@@ -229,8 +229,10 @@ def end_to_end(args, params, stream, n_distinct, rec, want_rgb, total, rank, wor
             kept[seq] = (idr, yuv.copy(), rgb.copy() if rgb is not None else None)
         return 1 if rc == 1 else 0
 
-    # cold call: creates the page-locked pools and device buffers; then the timed call on the same engine
-    rc0, st0 = eng.decode(h, order[:max(1, min(len(order), 64))], want_rgb=want_rgb)
+    # cold call (reported, not the metric): the same job once, so that the engine owns its page-locked pools and its
+    # device buffers at their working size; then the timed call on the same engine -- a service that decodes stream
+    # after stream is in that state
+    rc0, st0 = eng.decode(h, order, want_rgb=want_rgb)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize(dev)

@@ -86,6 +86,23 @@ typedef struct mvhp_mb_header {
     uint32_t reserved1;
 } mvhp_mb_header_t;
 
+/* ---------------------------------------------------------------------------
+ * Compact pictures: the transfer format between the host front end and the GPU (PCIe carries it instead of the packed
+ * records, of which most int16 slots are zero: ~140 instead of 800 bytes per macroblock on dense content).  One picture =
+ *     uint32 mb_off[W*H]          byte offset of each macroblock's compact record, counted from the end of this table
+ *     compact records, 4-byte aligned, in macroblock order:
+ *         mvhp_mb_header_t        as in the packed record, with reserved1 = number of entries that follow
+ *         uint32 entry[n]         one per non-zero level, in the order the entropy decoder delivered them:
+ *                                 bits 0-15 = int16 slot of the coefficient area (0..383), bits 16-31 = the level
+ *       or, for a macroblock of more than MVHP_COMPACT_MAX_ENTRIES levels, header.flags bit 0 set, reserved1 = 0 and
+ *       the 768-byte coefficient area itself.
+ * mvhp_expand_compact_dev() turns it into packed records on the device (a memory-bound pass of < 1 KB per macroblock);
+ * the packed record stays the input format of the reconstruction kernels.
+ * ------------------------------------------------------------------------- */
+#define MVHP_COMPACT_MAX_ENTRIES  191
+#define MVHP_COMPACT_MB_BYTES_MAX 804    /* 4 (offset) + 32 + 768: a picture needs at most W*H times this ...          */
+#define MVHP_COMPACT_SLACK_BYTES  1536   /* ... plus this (entries of one macroblock before it is found to be dense)   */
+
 /* Parameters shared by every picture of one batch (one SPS/PPS pair). */
 typedef struct mvhp_stream_params {
     uint32_t width_mbs;                      /* PicWidthInMbs                          */
@@ -135,6 +152,9 @@ MVHP_EXPORT int  mvhp_stream_params(const mvhp_stream_t *s, int idr, mvhp_stream
 /* Entropy-decode IDR picture `idr` into `packed` (mvhp_packed_frame_bytes()).
  * Thread-safe for distinct `idr` on the same handle. */
 MVHP_EXPORT int  mvhp_stream_decode_packed(const mvhp_stream_t *s, int idr, void *packed, size_t packed_bytes);
+/* The same into the compact transfer format; `cap` >= W*H * MVHP_COMPACT_MB_BYTES_MAX + MVHP_COMPACT_SLACK_BYTES,
+ * *used = bytes written. */
+MVHP_EXPORT int  mvhp_stream_decode_compact(const mvhp_stream_t *s, int idr, void *buf, size_t cap, size_t *used);
 MVHP_EXPORT const char *mvhp_stream_last_error(void);
 
 /* ---------------------------------------------------------------------------
@@ -154,6 +174,11 @@ MVHP_EXPORT const char *mvhp_last_error(void);
 MVHP_EXPORT int  mvhp_recon_batch_dev(mvhp_ctx_t *ctx, const mvhp_stream_params_t *p,
                                       const void *d_packed, int n_frames,
                                       uint8_t *d_yuv, uint8_t *d_rgb, void *stream);
+
+/* n_pictures compact pictures (see "Compact pictures" above), `stride` bytes apart in device memory, -> packed records
+ * (n_pictures * mvhp_packed_frame_bytes()) in device memory.  Asynchronous on `stream` (NULL = the context's own). */
+MVHP_EXPORT int  mvhp_expand_compact_dev(mvhp_ctx_t *ctx, const mvhp_stream_params_t *p, const void *d_compact,
+                                         size_t stride, int n_pictures, void *d_packed, void *stream);
 
 /* Same, but only the stages selected by `stages` (bit 0: reconstruction kernel,
  * bit 1: colour kernel) -- lets a caller bracket each kernel with its own events. */

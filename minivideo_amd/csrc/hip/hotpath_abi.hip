@@ -297,6 +297,25 @@ MVHP_EXPORT int mvhp_recon_batch_dev(mvhp_ctx_t *c, const mvhp_stream_params_t *
     return launch_all(c, p, d_packed, n_frames, d_yuv, d_rgb, st, true, true);
 }
 
+MVHP_EXPORT int mvhp_expand_compact_dev(mvhp_ctx_t *c, const mvhp_stream_params_t *p, const void *d_compact, size_t stride,
+                                        int n_pictures, void *d_packed, void *stream)
+{
+    if (!c || !params_ok(p) || !d_compact || !d_packed || n_pictures <= 0 || (stride & 3) ||
+        stride < (size_t)p->width_mbs * p->height_mbs * 4 + MVHP_MB_HEADER_BYTES) {
+        set_err("mvhp_expand_compact_dev: invalid argument");
+        return MVHP_FAILURE;
+    }
+    HIP_TRY(hipSetDevice(c->device));
+    mvhp::ExpandArgs a;
+    a.compact = (const uint8_t *)d_compact;
+    a.stride = stride;
+    a.packed = (uint8_t *)d_packed;
+    a.mbs = (int)(p->width_mbs * p->height_mbs);
+    a.n_pictures = n_pictures;
+    HIP_TRY(mvhp::launch_expand(a, stream ? (hipStream_t)stream : c->stream));
+    return MVHP_SUCCESS;
+}
+
 MVHP_EXPORT int mvhp_recon_stages_dev(mvhp_ctx_t *c, const mvhp_stream_params_t *p, const void *d_packed,
                                       int n_frames, uint8_t *d_yuv, uint8_t *d_rgb, void *stream, int stages)
 {
@@ -470,9 +489,16 @@ int eng_copy(DevCtx *d, hipStream_t st, hipEvent_t e0, hipEvent_t e1, void *dst,
     return MVHP_SUCCESS;
 }
 
-int eng_h2d(DevCtx *d, void *dst, const void *src, size_t bytes, float *ms, std::string &err)
+int eng_h2d(DevCtx *d, int n, void *const *dst, const void *const *src, const size_t *bytes, float *ms, std::string &err)
 {
-    return eng_copy(d, d->up, d->ev[0], d->ev[1], dst, src, bytes, hipMemcpyHostToDevice, ms, err);
+    ENG_TRY(hipSetDevice(d->c->device));
+    ENG_TRY(hipEventRecord(d->ev[0], d->up));
+    for (int i = 0; i < n; i++)
+        if (bytes[i]) ENG_TRY(hipMemcpyAsync(dst[i], src[i], bytes[i], hipMemcpyHostToDevice, d->up));
+    ENG_TRY(hipEventRecord(d->ev[1], d->up));
+    ENG_TRY(hipEventSynchronize(d->ev[1]));
+    if (ms) ENG_TRY(hipEventElapsedTime(ms, d->ev[0], d->ev[1]));
+    return MVHP_SUCCESS;
 }
 
 int eng_d2h(DevCtx *d, void *dst, const void *src, size_t bytes, float *ms, std::string &err)
@@ -480,13 +506,14 @@ int eng_d2h(DevCtx *d, void *dst, const void *src, size_t bytes, float *ms, std:
     return eng_copy(d, d->down, d->ev[4], d->ev[5], dst, src, bytes, hipMemcpyDeviceToHost, ms, err);
 }
 
-int eng_recon(DevCtx *d, const mvhp_stream_params_t *p, const void *d_packed, int n, uint8_t *d_yuv, uint8_t *d_rgb, float *ms,
-              int *layout, int *waves, std::string &err)
+int eng_recon(DevCtx *d, const mvhp_stream_params_t *p, const void *d_compact, size_t stride, void *d_packed, int n, uint8_t *d_yuv,
+              uint8_t *d_rgb, float *ms, int *layout, int *waves, std::string &err)
 {
     mvhp_ctx *c = d->c;
-    if (!params_ok(p) || !d_packed || !d_yuv || n <= 0) { err = "reconstruction: invalid argument"; return MVHP_FAILURE; }
+    if (!params_ok(p) || !d_compact || !d_packed || !d_yuv || n <= 0) { err = "reconstruction: invalid argument"; return MVHP_FAILURE; }
     ENG_TRY(hipSetDevice(c->device));
     ENG_TRY(hipEventRecord(d->ev[2], c->stream));
+    if (mvhp_expand_compact_dev(c, p, d_compact, stride, n, d_packed, c->stream) != MVHP_SUCCESS) { err = mvhp_last_error(); return MVHP_FAILURE; }
     const int rc = launch_all(c, p, d_packed, n, d_yuv, d_rgb, c->stream, true, true);
     if (rc != MVHP_SUCCESS) { err = mvhp_last_error(); return rc; }
     ENG_TRY(hipEventRecord(d->ev[3], c->stream));

@@ -18,6 +18,13 @@ struct ReconArgs {
                                     // `qP > 36` (h264_transform.c:797), 36 = the standard (MVHP_PARAM_SPEC_LUMA_DC)
 };
 
+struct ExpandArgs {
+    const uint8_t *compact;  // n_pictures compact pictures, `stride` bytes apart
+    size_t         stride;
+    uint8_t       *packed;   // n_pictures * mbs * 800 B packed records (output)
+    int            mbs, n_pictures;
+};
+
 struct ColorArgs {
     const uint8_t *yuv;
     uint8_t       *rgb;
@@ -33,5 +40,6 @@ hipError_t launch_recon_quad(const ReconArgs &a, int nw, hipStream_t stream);
 size_t     recon_oct_lds_bytes(int width_mbs, int nw);
 hipError_t launch_recon_oct(const ReconArgs &a, int nw, hipStream_t stream);
 hipError_t launch_color(const ColorArgs &a, hipStream_t stream);
+hipError_t launch_expand(const ExpandArgs &a, hipStream_t stream);
 
 } // namespace mvhp

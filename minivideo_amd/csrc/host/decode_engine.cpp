@@ -4,7 +4,8 @@
 //   feeder              hands out pictures in `order`, never more than `wanted` minus what is already accepted or in
 //                       flight (the reference stops after picture_number IDRs, h264.c:173-179), grouped into chunks
 //                       (one H2D transfer) and batches (one kernel launch, one set of stream parameters);
-//   T entropy workers   mvhp_stream::decode_packed() straight into a page-locked chunk slot;
+//   T entropy workers   mvhp_stream::decode_compact() straight into a page-locked chunk slot (the compact transfer
+//                       format: only non-zero levels cross PCIe; the GPU expands it into packed records);
 //   per context:        uploader (claims whole batches from the shared queue: pictures are independent, so this is
 //                       the frame-level work queue of SURVEY 8e -- no collective), launcher, downloader;
 //   caller thread       calls the sink once per picture, in order.
@@ -79,11 +80,12 @@ struct Pinned {
 };
 
 struct InChunk {
-    Pinned buf;
+    Pinned buf;              // n slots of pic_bytes: one compact picture each (include/minivideo_hotpath.h)
     int batch = -1;
     int first_slot = 0;      // picture offset inside the batch
     int n = 0;               // pictures in this chunk
-    size_t pic_bytes = 0;
+    size_t pic_bytes = 0;    // slot size = the most a compact picture of these parameters can take
+    std::vector<size_t> used;// bytes of each slot actually written
     int remaining = 0;       // pictures not yet entropy-decoded (guarded by the engine mutex)
 };
 
@@ -104,11 +106,27 @@ struct PicResult {
 };
 
 struct DevBuf {
-    void *packed = nullptr;
+    void *compact = nullptr; // uploaded compact pictures, slot stride as in the chunks
+    void *packed = nullptr;  // the records they expand to
     uint8_t *yuv = nullptr, *rgb = nullptr;
-    size_t packed_cap = 0, yuv_cap = 0, rgb_cap = 0;
+    size_t compact_cap = 0, packed_cap = 0, yuv_cap = 0, rgb_cap = 0;
     bool busy = false;
 };
+
+// slot size of a compact picture: the format's upper bound, 16-byte aligned
+size_t compact_slot_bytes(const mvhp_stream_params_t &p)
+{
+    const size_t mbs = (size_t)p.width_mbs * p.height_mbs;
+    return (mbs * MVHP_COMPACT_MB_BYTES_MAX + MVHP_COMPACT_SLACK_BYTES + 15) & ~(size_t)15;
+}
+
+// a valid compact picture without a single level (every offset points at one empty Intra4x4 record): what a slot holds
+// when its picture failed to parse, so that the batch can still be expanded
+size_t write_empty_compact(uint8_t *buf, size_t mbs)
+{
+    memset(buf, 0, mbs * 4 + MVHP_MB_HEADER_BYTES);
+    return mbs * 4 + MVHP_MB_HEADER_BYTES;
+}
 
 struct Batch {
     int id = 0;
@@ -214,6 +232,7 @@ Engine::~Engine()
     for (auto &c : all_out_) { api_.host_free(c->yuv.p); api_.host_free(c->rgb.p); }
     for (Ctx &c : ctx_) {
         for (DevBuf &b : c.bufs) {
+            if (b.compact) api_.dev_free(c.dev, b.compact);
             if (b.packed) api_.dev_free(c.dev, b.packed);
             if (b.yuv) api_.dev_free(c.dev, b.yuv);
             if (b.rgb) api_.dev_free(c.dev, b.rgb);
@@ -277,23 +296,30 @@ int Engine::chunk_pictures(const mvhp_stream_params_t &p) const
     return (int)std::min<size_t>(64, std::max<size_t>(1, ((size_t)64 << 20) / pb));
 }
 
-// pictures per launch.  Speed only: the batch kernels want >= 3 x CUs (four pictures per workgroup) or >= 8 x CUs
-// (eight) pictures, but the host entropy stage is the slower side by far, so what matters is the END of a job: the last
-// batch's kernel and download are not hidden behind any entropy work.  Batches therefore taper -- each takes at most half
-// of what is left per context, down to 64 pictures (1024, 512, 256, 128, 64, 64 for 2048 pictures: the exposed tail is the
-// download of 64 pictures instead of 1024) -- never more than one context's share, the cap, or the device memory budget.
+// pictures per launch.  Speed only.  The batch kernels want >= 3 x CUs (four pictures per workgroup) or >= 8 x CUs
+// (eight) pictures, but the host entropy stage is the slow side and the download of a batch (9.4 MB per 1080p picture) is
+// next: what matters is that downloads start early and that the job's last download is short.  So batches RAMP UP from 64
+// pictures, doubling, to the cap (the download of batch k hides behind the entropy work of batch k+1 as long as batches
+// do not shrink faster than the link is quicker than the entropy stage), and TAPER at the end (each takes at most 35 %
+// of what is left per context, down to 64): 64 128 256 512 381 248 161 105 68 64 61 for 2048 pictures on one context;
+// long jobs run most of their pictures in 1024-picture launches.  Modelled wall for 2048 x 1080p: 0.56 s against 0.63 s
+// with 1024 512 256 128 64 64 and 0.535 s of pure entropy work.
 int Engine::batch_capacity(const mvhp_stream_params_t &p, int remaining) const
 {
     const int n_ctx = (int)ctx_.size();
     int cap = opts_.batch_pictures > 0 ? opts_.batch_pictures : 1024;
-    const size_t per_pic = mvhp_packed_frame_bytes(&p) + mvhp_yuv_frame_bytes(&p) + (want_rgb_ ? mvhp_rgb_frame_bytes(&p) : 0);
+    const size_t per_pic = compact_slot_bytes(p) + mvhp_packed_frame_bytes(&p) + mvhp_yuv_frame_bytes(&p) +
+                           (want_rgb_ ? mvhp_rgb_frame_bytes(&p) : 0);
     size_t budget = ctx_[0].mem_budget;
     for (const Ctx &c : ctx_) budget = std::min(budget, c.mem_budget);
     const int mem_cap = (int)std::min<size_t>(1 << 20, std::max<size_t>(1, budget / std::max<size_t>(1, per_pic)));
     cap = std::min(cap, mem_cap);
     const int share = (remaining + n_ctx - 1) / n_ctx;
-    const int taper = opts_.batch_pictures > 0 ? cap : std::max(64, (remaining + 2 * n_ctx - 1) / (2 * n_ctx));   // (an explicit batch size is taken as given)
-    return std::max(1, std::min(cap, std::min(share, taper)));
+    if (opts_.batch_pictures > 0) return std::max(1, std::min(cap, share));   // an explicit batch size is taken as given
+    const int round = next_batch_id_ / n_ctx;                                   // batches each context has been given so far
+    const int ramp = round < 5 ? (64 << round) : cap;
+    const int taper = std::max(64, (int)((remaining * 0.35 + n_ctx - 1) / n_ctx));
+    return std::max(1, std::min(std::min(cap, ramp), std::min(share, taper)));
 }
 
 bool Engine::ensure_devbuf(Ctx &c, DevBuf &b, const Batch &bt, std::string &err)
@@ -306,7 +332,8 @@ bool Engine::ensure_devbuf(Ctx &c, DevBuf &b, const Batch &bt, std::string &err)
         return *ptr != nullptr;
     };
     const size_t n = (size_t)bt.capacity;
-    if (!need(&b.packed, &b.packed_cap, n * mvhp_packed_frame_bytes(&bt.params)) ||
+    if (!need(&b.compact, &b.compact_cap, n * compact_slot_bytes(bt.params)) ||
+        !need(&b.packed, &b.packed_cap, n * mvhp_packed_frame_bytes(&bt.params)) ||
         !need((void **)&b.yuv, &b.yuv_cap, n * mvhp_yuv_frame_bytes(&bt.params)) ||
         (want_rgb_ && !need((void **)&b.rgb, &b.rgb_cap, n * mvhp_rgb_frame_bytes(&bt.params)))) {
         err = "out of device memory for a batch of " + std::to_string(bt.capacity) + " pictures";
@@ -390,7 +417,7 @@ void Engine::feeder()
         n = same;
         // a free page-locked chunk (the pool grows up to its limit; page-locking happens outside the lock)
         InChunk *c = nullptr;
-        const size_t pic_bytes = mvhp_packed_frame_bytes(&p0);
+        const size_t pic_bytes = compact_slot_bytes(p0);
         for (;;) {
             if (stop_) break;
             if (!free_in_.empty()) { c = free_in_.front(); free_in_.pop_front(); break; }
@@ -422,6 +449,7 @@ void Engine::feeder()
             c->first_slot = (int)cur->seqs.size();
             c->n = n;
             c->pic_bytes = pic_bytes;
+            c->used.assign((size_t)n, 0);
             c->remaining = n;
             for (int i = 0; i < n; i++) {
                 const int seq = seq_at(i);
@@ -472,7 +500,14 @@ void Engine::worker(int t)
         const int idr = order_[it.seq];
         std::string err;
         const double t0 = now_s();
-        const int rc = s_->decode_packed(idr, it.chunk->buf.p + (size_t)it.slot * it.chunk->pic_bytes, it.chunk->pic_bytes, err);
+        uint8_t *slot = it.chunk->buf.p + (size_t)it.slot * it.chunk->pic_bytes;
+        size_t used = 0;
+        const int rc = s_->decode_compact(idr, slot, it.chunk->pic_bytes, &used, err);
+        if (rc != h264::RC_SUCCESS) {   // the slot still has to expand to something: an empty picture
+            const mvhp_stream::Idr &d = s_->idrs[(size_t)idr];
+            used = write_empty_compact(slot, (size_t)d.sps.width_mbs * (size_t)d.sps.height_map_units);
+        }
+        it.chunk->used[(size_t)it.slot] = used;   // (each slot has one writer; read by the uploader behind the engine mutex)
         worker_busy_[(size_t)t] += now_s() - t0;
         if (idr >= 0 && (size_t)idr < s_->idrs.size()) stream_bytes_ += s_->samples[s_->idrs[(size_t)idr].sample].nal_size;
         {
@@ -578,8 +613,15 @@ void Engine::uploader(int k)
         bool ok = !b->dead;
         if (ok) ok = ensure_devbuf(cx, *b->buf, *b, err);   // sized once per batch (capacity is fixed when it opens)
         if (ok) {
-            const size_t bytes = (size_t)c->n * c->pic_bytes;
-            ok = api_.h2d(cx.dev, (uint8_t *)b->buf->packed + (size_t)c->first_slot * c->pic_bytes, c->buf.p, bytes, &ms, err) == MVHP_SUCCESS;
+            std::vector<void *> dst((size_t)c->n);
+            std::vector<const void *> src((size_t)c->n);
+            size_t bytes = 0;
+            for (int i = 0; i < c->n; i++) {   // only what the entropy stage wrote crosses the link
+                dst[(size_t)i] = (uint8_t *)b->buf->compact + (size_t)(c->first_slot + i) * c->pic_bytes;
+                src[(size_t)i] = c->buf.p + (size_t)i * c->pic_bytes;
+                bytes += c->used[(size_t)i];
+            }
+            ok = api_.h2d(cx.dev, c->n, dst.data(), src.data(), c->used.data(), &ms, err) == MVHP_SUCCESS;
             if (ok) {
                 std::lock_guard<std::mutex> l(mu_);
                 st_.h2d_s += ms * 1e-3;
@@ -620,8 +662,8 @@ void Engine::launcher(int k)
         int layout = 0, waves = 0;
         int rc = MVHP_SUCCESS;
         if (inject) { rc = MVHP_FAILURE; err = "injected failure (test hook)"; }
-        else rc = api_.recon(cx.dev, &b->params, b->buf->packed, b->total, b->buf->yuv, want_rgb_ ? b->buf->rgb : nullptr, &ms,
-                             &layout, &waves, err);
+        else rc = api_.recon(cx.dev, &b->params, b->buf->compact, compact_slot_bytes(b->params), b->buf->packed, b->total,
+                             b->buf->yuv, want_rgb_ ? b->buf->rgb : nullptr, &ms, &layout, &waves, err);
         {
             std::lock_guard<std::mutex> l(mu_);
             if (rc == MVHP_SUCCESS) {

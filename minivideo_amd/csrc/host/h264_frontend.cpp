@@ -232,22 +232,46 @@ PictureDecoder::PictureDecoder(const Sps &sps, const Pps &pps, int nal_ref_idc)
 
 PictureDecoder::~PictureDecoder() { delete cabac_; }
 
-int PictureDecoder::decode(const uint8_t *rbsp, size_t n, uint8_t *packed, size_t packed_bytes, std::string &err)
+int PictureDecoder::run(std::string &err)
 {
-    if ((size_t)W_ * H_ * MVHP_MB_BYTES != packed_bytes) { err = "packed buffer size mismatch"; return RC_FAILURE; }
-    br_ = BitReader(rbsp, n);
-    out_ = packed;   // (every record is zeroed right before its macroblock is parsed: macroblock())
     mbs_.assign((size_t)W_ * H_, MbState());
     level_overflow_ = false;
     int rc = slice_header(err);
     if (rc != RC_SUCCESS) return rc;
     rc = slice_data(err);
-    if (rc != RC_SUCCESS) {   // the records behind the failure were never written: leave no stale bytes in the buffer
-        memset(out_, 0, packed_bytes);
-        return rc;
-    }
+    if (rc != RC_SUCCESS) return rc;
     if (level_overflow_) { err = "transform coefficient level outside int16"; return RC_FAILURE; }
     return RC_SUCCESS;
+}
+
+int PictureDecoder::decode(const uint8_t *rbsp, size_t n, uint8_t *packed, size_t packed_bytes, std::string &err)
+{
+    if ((size_t)W_ * H_ * MVHP_MB_BYTES != packed_bytes) { err = "packed buffer size mismatch"; return RC_FAILURE; }
+    br_ = BitReader(rbsp, n);
+    out_ = packed;   // (every record is zeroed right before its macroblock is parsed: macroblock())
+    compact_ = false;
+    const int rc = run(err);
+    if (rc != RC_SUCCESS) memset(out_, 0, packed_bytes);   // the records behind a failure were never written: no stale bytes
+    return rc;
+}
+
+int PictureDecoder::decode_compact(const uint8_t *rbsp, size_t n, uint8_t *buf, size_t cap, size_t *used, std::string &err)
+{
+    const size_t mbs = (size_t)W_ * H_;
+    if (cap < mbs * MVHP_COMPACT_MB_BYTES_MAX + MVHP_COMPACT_SLACK_BYTES) { err = "compact buffer too small"; return RC_FAILURE; }
+    br_ = BitReader(rbsp, n);
+    out_ = nullptr;
+    compact_ = true;
+    mb_off_ = reinterpret_cast<uint32_t *>(buf);
+    cw_base_ = cw_ = buf + mbs * 4;
+    compact_max_ = MVHP_COMPACT_MAX_ENTRIES;
+    if (const char *e = getenv("MINIVIDEO_TEST_COMPACT_MAX")) {   // test hook: exercise the dense fallback on ordinary streams
+        const int v = atoi(e);
+        if (v >= 0 && v < MVHP_COMPACT_MAX_ENTRIES) compact_max_ = (uint32_t)v;
+    }
+    const int rc = run(err);
+    if (used) *used = rc == RC_SUCCESS ? (size_t)(cw_ - buf) : 0;
+    return rc;
 }
 
 // H6: decodeSliceHeader, h264_slice.c:156-334 (IDR / I slices only)
@@ -387,7 +411,11 @@ int PictureDecoder::macroblock(int addr, std::string &err)
 {
     MbState &mb = mbs_[addr];
     const bool cabac = pps_.entropy_coding_mode;
-    memset(out_ + (size_t)addr * MVHP_MB_BYTES, 0, MVHP_MB_BYTES);   // levels are written sparsely into a zero record
+    if (compact_) cwl_ = reinterpret_cast<uint32_t *>(cw_ + MVHP_MB_HEADER_BYTES);   // entries follow the header (written last)
+    else {
+        memset(out_ + (size_t)addr * MVHP_MB_BYTES, 0, MVHP_MB_BYTES);   // levels are written sparsely into a zero record
+        coef_ = reinterpret_cast<int16_t *>(out_ + (size_t)addr * MVHP_MB_BYTES + MVHP_MB_HEADER_BYTES);
+    }
     const unsigned mb_type = cabac ? cabac_->mb_type(addr) : br_.ue();
     if (mb_type == 25) { err = "I_PCM macroblocks are not supported"; return RC_UNSUPPORTED; } // :151-154
     if (mb_type > 25) { err = "invalid mb_type in an I slice"; return RC_FAILURE; }
@@ -458,12 +486,33 @@ int PictureDecoder::macroblock(int addr, std::string &err)
     h.chroma_pred_mode = mb.chroma_pred_mode;
     h.i16_pred_mode = (uint8_t)i16_mode;
     memcpy(h.pred_mode, mb.pred, 16);
-    uint8_t *rec = out_ + (size_t)addr * MVHP_MB_BYTES;
     uint32_t nz = nz_cur_;   // collected while the blocks were decoded: every decoded level is non-zero
     if (mb.kind == MVHP_KIND_I8x8)
         for (int k = 0; k < 4; k++)
             if (nz & (0xfu << (4 * k))) nz |= 0xfu << (4 * k);
     h.nz_mask = nz;
+    if (!compact_) {
+        memcpy(out_ + (size_t)addr * MVHP_MB_BYTES, &h, sizeof(h));
+        return RC_SUCCESS;
+    }
+    // compact record: header (reserved1 = number of entries) + one 32-bit entry per level; a macroblock with more than
+    // MVHP_COMPACT_MAX_ENTRIES levels is sent as its dense coefficient area instead (flags bit 0)
+    uint8_t *rec = cw_;
+    mb_off_[addr] = (uint32_t)(rec - cw_base_);
+    uint32_t *ent = reinterpret_cast<uint32_t *>(rec + MVHP_MB_HEADER_BYTES);
+    const uint32_t n = (uint32_t)(cwl_ - ent);
+    if (n > compact_max_) {
+        int16_t dense[MVHP_MB_COEFS];
+        memset(dense, 0, sizeof(dense));
+        for (uint32_t i = 0; i < n; i++) dense[ent[i] & 0xffffu] = (int16_t)(ent[i] >> 16);
+        memcpy(ent, dense, sizeof(dense));
+        h.flags = 1;
+        h.reserved1 = 0;
+        cw_ = rec + MVHP_MB_HEADER_BYTES + sizeof(dense);
+    } else {
+        h.reserved1 = n;
+        cw_ = reinterpret_cast<uint8_t *>(cwl_);
+    }
     memcpy(rec, &h, sizeof(h));
     return RC_SUCCESS;
 }
@@ -496,30 +545,30 @@ const SinkTables g_sink;
 
 void PictureDecoder::sink_begin(int addr, int cat, int blkIdx, int part)
 {
-    int16_t *coef = reinterpret_cast<int16_t *>(out_ + (size_t)addr * MVHP_MB_BYTES + MVHP_MB_HEADER_BYTES);
+    (void)addr;
     sink_.scale = 1;
     sink_.nz_per_coef = false;
     switch (cat) {
     case CAT_LUMA_8x8:
         if (part >= 0) { sink_.tab = g_sink.l8i[part]; }
         else sink_.tab = g_sink.l8;
-        sink_.dst = coef + blkIdx * 64;
+        sink_.base = blkIdx * 64;
         sink_.nz_bit = 0xfu << (4 * blkIdx);
         break;
-    case CAT_LUMA_4x4: sink_.tab = g_sink.l4; sink_.dst = coef + blkIdx * 16; sink_.nz_bit = 1u << blkIdx; break;
+    case CAT_LUMA_4x4: sink_.tab = g_sink.l4; sink_.base = blkIdx * 16; sink_.nz_bit = 1u << blkIdx; break;
     case CAT_LUMA_16x16_DC:   // c1[row][col] -> slot 0 of the block at that raster position
-        sink_.tab = g_sink.dc16; sink_.dst = coef; sink_.scale = 16; sink_.nz_bit = 1u; sink_.nz_per_coef = true;
+        sink_.tab = g_sink.dc16; sink_.base = 0; sink_.scale = 16; sink_.nz_bit = 1u; sink_.nz_per_coef = true;
         break;
-    case CAT_LUMA_16x16_AC: sink_.tab = g_sink.ac; sink_.dst = coef + blkIdx * 16; sink_.nz_bit = 1u << blkIdx; break;
+    case CAT_LUMA_16x16_AC: sink_.tab = g_sink.ac; sink_.base = blkIdx * 16; sink_.nz_bit = 1u << blkIdx; break;
     case CAT_CHROMA_DC_CB:
     case CAT_CHROMA_DC_CR: {   // DC level k -> slot 0 of chroma block k
         static const uint8_t ident[4] = {0, 1, 2, 3};
-        sink_.tab = ident; sink_.dst = coef + 256 + (cat - CAT_CHROMA_DC_CB) * 64; sink_.scale = 16;
+        sink_.tab = ident; sink_.base = 256 + (cat - CAT_CHROMA_DC_CB) * 64; sink_.scale = 16;
         sink_.nz_bit = 1u << (16 + 4 * (cat - CAT_CHROMA_DC_CB)); sink_.nz_per_coef = true;
         break;
     }
     default:   // chroma AC
-        sink_.tab = g_sink.ac; sink_.dst = coef + 256 + (cat - CAT_CHROMA_AC_CB) * 64 + blkIdx * 16;
+        sink_.tab = g_sink.ac; sink_.base = 256 + (cat - CAT_CHROMA_AC_CB) * 64 + blkIdx * 16;
         sink_.nz_bit = 1u << (16 + 4 * (cat - CAT_CHROMA_AC_CB) + blkIdx);
         break;
     }

@@ -100,6 +100,9 @@ public:
     ~PictureDecoder();
     // rbsp: slice NAL payload (after the NAL header byte), emulation prevention removed.
     int decode(const uint8_t *rbsp, size_t n, uint8_t *packed, size_t packed_bytes, std::string &err);
+    // The same picture in the COMPACT transfer format (include/minivideo_hotpath.h, "compact pictures"): the levels that
+    // are zero -- most of an 800-byte record -- never cross the PCIe link; the GPU expands it into packed records.
+    int decode_compact(const uint8_t *rbsp, size_t n, uint8_t *buf, size_t cap, size_t *used, std::string &err);
 
 private:
     friend struct CabacEngine;
@@ -112,7 +115,7 @@ private:
     int  nC_for(int addr, int cat, int blkIdx) const;
     // destination of the block being decoded: coefficient index -> int16 slot of the packed record
     struct Sink {
-        int16_t       *dst = nullptr;
+        int            base = 0;              // first int16 slot (0..383) of the block inside the coefficient area
         const uint8_t *tab = nullptr;
         int            scale = 1;
         uint32_t       nz_bit = 0;
@@ -123,7 +126,12 @@ private:
     {
         if (v > 32767 || v < -32768) { level_overflow_ = true; v = 0; }
         const int slot = sink_.tab[idx];
-        sink_.dst[slot * sink_.scale] = (int16_t)v;
+        const int pos = sink_.base + slot * sink_.scale;
+        if (compact_) {   // one entry per level, in the order the entropy decoder delivers them
+            *cwl_++ = ((uint32_t)(uint16_t)v << 16) | (uint32_t)pos;
+        } else {
+            coef_[pos] = (int16_t)v;
+        }
         nz_cur_ |= sink_.nz_per_coef ? (sink_.nz_bit << slot) : sink_.nz_bit;
     }
 
@@ -142,6 +150,13 @@ private:
     CabacEngine *cabac_ = nullptr;
     bool       level_overflow_ = false;
     Sink       sink_;
+    int16_t   *coef_ = nullptr;  // dense output: coefficient area of the macroblock being parsed
+    bool       compact_ = false; // compact output: the writer (cw_ = record of the macroblock being parsed, cwl_ = its next entry)
+    uint8_t   *cw_ = nullptr, *cw_base_ = nullptr;
+    uint32_t  *cwl_ = nullptr;
+    uint32_t   compact_max_ = MVHP_COMPACT_MAX_ENTRIES;
+    uint32_t  *mb_off_ = nullptr;
+    int  run(std::string &err);
     int        cur_addr_ = -1, curA_ = -1, cur_x_ = 0;   // the macroblock being parsed, its left neighbour, its column
     uint32_t   nz_cur_ = 0;      // nz_mask of the macroblock being decoded
 };

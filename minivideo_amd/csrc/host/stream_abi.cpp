@@ -144,6 +144,19 @@ int mvhp_stream::decode_packed(int k, void *packed, size_t bytes, std::string &e
     return pd.decode(rbsp.data(), rbsp.size(), (uint8_t *)packed, bytes, err);
 }
 
+int mvhp_stream::decode_compact(int k, void *buf, size_t cap, size_t *used, std::string &err) const
+{
+    if (used) *used = 0;
+    if (k < 0 || (size_t)k >= idrs.size()) { err = "IDR index out of range"; return RC_FAILURE; }
+    const Idr &idr = idrs[k];
+    if (!idr.ok) { err = idr.why; return RC_FAILURE; }
+    const EsSample &s = samples[idr.sample];
+    std::vector<uint8_t> rbsp;
+    unescape_rbsp(data + s.offset + 1, s.nal_size - 1, rbsp);
+    PictureDecoder pd(idr.sps, idr.pps, s.nal_ref_idc);
+    return pd.decode_compact(rbsp.data(), rbsp.size(), (uint8_t *)buf, cap, used, err);
+}
+
 static thread_local std::string g_stream_err;
 
 extern "C" {
@@ -208,6 +221,15 @@ MVHP_EXPORT int mvhp_stream_decode_packed(const mvhp_stream_t *s, int idr, void 
     if (!s || !packed) return MVHP_FAILURE;
     std::string err;
     const int rc = s->decode_packed(idr, packed, packed_bytes, err);
+    if (rc != RC_SUCCESS) g_stream_err = err;
+    return rc;
+}
+
+MVHP_EXPORT int mvhp_stream_decode_compact(const mvhp_stream_t *s, int idr, void *buf, size_t cap, size_t *used)
+{
+    if (!s || !buf) return MVHP_FAILURE;
+    std::string err;
+    const int rc = s->decode_compact(idr, buf, cap, used, err);
     if (rc != RC_SUCCESS) g_stream_err = err;
     return rc;
 }

@@ -23,4 +23,5 @@ struct mvhp_stream {
     int build(std::string &err);      // Annex-B elementary stream
     int build_mp4(std::string &err);  // ISO-BMFF: avcC parameter sets + length-prefixed NAL units of the sync samples
     int decode_packed(int idr, void *packed, size_t bytes, std::string &err) const;
+    int decode_compact(int idr, void *buf, size_t cap, size_t *used, std::string &err) const;
 };

@@ -78,6 +78,8 @@ def lib():
     L.mvhp_set_fused_color.argtypes = [vp, i32]
     L.mvhp_recon_batch_dev.restype = i32
     L.mvhp_recon_batch_dev.argtypes = [vp, pp, vp, i32, vp, vp, vp]
+    L.mvhp_expand_compact_dev.restype = i32
+    L.mvhp_expand_compact_dev.argtypes = [vp, pp, vp, sz, i32, vp, vp]
     L.mvhp_recon_stages_dev.restype = i32
     L.mvhp_recon_stages_dev.argtypes = [vp, pp, vp, i32, vp, vp, vp, i32]
     L.mvhp_recon_batch_host.restype = i32
@@ -161,6 +163,12 @@ class HotPath:
         rc = self._L.mvhp_recon_batch_dev(self._h, C.byref(params), d_packed, int(n_frames), d_yuv, d_rgb, stream)
         if rc != SUCCESS:
             raise _err(self._L, "mvhp_recon_batch_dev")
+
+    def expand_compact_dev(self, params, d_compact, stride, n_pictures, d_packed, stream=None):
+        """compact pictures (transfer format) -> packed records, both in device memory"""
+        rc = self._L.mvhp_expand_compact_dev(self._h, C.byref(params), d_compact, int(stride), int(n_pictures), d_packed, stream)
+        if rc != SUCCESS:
+            raise _err(self._L, "mvhp_expand_compact_dev")
 
     def recon_stages_dev(self, params, d_packed, n_frames, d_yuv, d_rgb, stream, stages):
         rc = self._L.mvhp_recon_stages_dev(self._h, C.byref(params), d_packed, int(n_frames), d_yuv, d_rgb,

@@ -168,3 +168,37 @@ def test_tiny_stream_announcing_a_huge_picture_is_rejected_before_allocation():
         assert s.params(0) is None            # no parameters handed out: nobody sizes a buffer from this SPS
         rc, _ = s.packed(0)
         assert rc != 1
+
+
+@pytest.mark.parametrize("profile", ["baseline", "main", "high", "high_cavlc"])
+def test_compact_pictures_expand_to_the_packed_records(profile):
+    """The compact transfer format (what crosses PCIe) carries exactly the packed records: expanded by the reference
+    expander of tests/compact.py it equals mvhp_stream_decode_packed byte for byte, and is several times smaller."""
+    from tests.compact import decode_compact, expand
+    stream, packed = gen.make_stream(9, 7, 3, seed=61, profile=profile)
+    with Stream(stream) as s:
+        for k in range(3):
+            rc, used, buf = decode_compact(s, k)
+            assert rc == 1 and 0 < used < 63 * 800 // 2
+            assert np.array_equal(expand(buf, 63), packed[k])
+            rc2, dense = s.packed(k)
+            assert rc2 == 1 and np.array_equal(dense.reshape(63, 800), packed[k])
+
+
+def test_compact_dense_fallback_for_crowded_macroblocks(monkeypatch):
+    """a macroblock with more than 191 levels travels as its dense coefficient area (flags bit 0): never more than
+    804 bytes per macroblock, whatever the stream.  The generator's content stays far below 191 levels per macroblock,
+    so the threshold is lowered through the test hook."""
+    from tests.compact import COMPACT_MB_BYTES_MAX, decode_compact, expand
+    stream, packed = gen.make_stream(4, 3, 2, seed=62, profile="high", qp_range=(0, 4), max_level=6)
+    nnz = (packed[:, :, 32:].view(np.int16) != 0).sum(axis=-1)
+    assert nnz.max() > 12
+    monkeypatch.setenv("MINIVIDEO_TEST_COMPACT_MAX", "12")
+    with Stream(stream) as s:
+        for k in range(2):
+            rc, used, buf = decode_compact(s, k)
+            assert rc == 1 and used <= 12 * COMPACT_MB_BYTES_MAX
+            off = buf[:48].view(np.uint32)
+            flags = np.array([buf[48 + int(o) + 5] for o in off])
+            assert np.array_equal(flags == 1, nnz[k] > 12)          # exactly the crowded macroblocks went dense
+            assert np.array_equal(expand(buf, 12), packed[k])

@@ -168,3 +168,33 @@ def test_cli_requeue_through_the_api(tmp_path):
              env={"MINIVIDEO_FAKE_GPUS": "2", "MINIVIDEO_BATCH": "8", "MINIVIDEO_TEST_FAIL_CONTEXT": "1"})
     assert f"{F} written" in r.stderr and f"{F + 8} pictures entropy-decoded" in r.stderr, r.stderr
     assert all(os.path.exists(tmp_path / f"clip_{k}.bmp") for k in range(F))
+
+
+@pytest.mark.parametrize("profile,threshold", [("baseline", None), ("high", None), ("high", "12"), ("main", "0")])
+def test_expand_kernel_matches_the_packed_records(profile, threshold, monkeypatch):
+    """mvhp_expand_compact_dev: compact pictures (what crosses PCIe) -> packed records, byte for byte what
+    mvhp_stream_decode_packed writes -- also with macroblocks sent as dense coefficient areas (threshold lowered through
+    the test hook; 0 = every macroblock that has a level)."""
+    import torch
+    from minivideo_amd import HotPath
+    from tests.compact import COMPACT_MB_BYTES_MAX, COMPACT_SLACK_BYTES, decode_compact
+    if threshold is not None:
+        monkeypatch.setenv("MINIVIDEO_TEST_COMPACT_MAX", threshold)
+    W, H, F = 13, 7, 5
+    stream, packed = gen.make_stream(W, H, F, seed=88, profile=profile)
+    stride = (W * H * COMPACT_MB_BYTES_MAX + COMPACT_SLACK_BYTES + 15) & ~15
+    host = np.zeros((F, stride), np.uint8)
+    with Stream(stream) as s:
+        p = s.params(0)
+        for k in range(F):
+            rc, used, buf = decode_compact(s, k)
+            assert rc == 1
+            host[k, :used] = buf[:used]
+    d_compact = torch.from_numpy(host).cuda()
+    d_packed = torch.full((F * W * H * 800,), 0xEE, dtype=torch.uint8, device="cuda")
+    hot = HotPath(0)
+    hot.expand_compact_dev(p, d_compact.data_ptr(), stride, F, d_packed.data_ptr())
+    hot.sync_check()
+    hot.close()
+    got = d_packed.cpu().numpy().reshape(F, W * H, 800)
+    assert np.array_equal(got, packed)

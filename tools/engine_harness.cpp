@@ -53,7 +53,7 @@ DevCtx *stub_ctx_create(int device, std::string &) { g_live_ctx++; return new De
 void stub_ctx_destroy(DevCtx *c) { g_live_ctx--; delete c; }
 void *stub_dev_alloc(DevCtx *, size_t n) { g_dev_allocs++; return malloc(n ? n : 1); }
 void stub_dev_free(DevCtx *, void *p) { g_dev_allocs--; free(p); }
-size_t stub_dev_free_bytes(DevCtx *) { return (size_t)1 << 30; }
+size_t stub_dev_free_bytes(DevCtx *) { return (size_t)1 << 32; }
 int stub_copy(DevCtx *, void *dst, const void *src, size_t n, float *ms, std::string &)
 {
     memcpy(dst, src, n);
@@ -61,11 +61,43 @@ int stub_copy(DevCtx *, void *dst, const void *src, size_t n, float *ms, std::st
     if (ms) *ms = 0.05f;
     return MVHP_SUCCESS;
 }
-int stub_recon(DevCtx *, const mvhp_stream_params_t *p, const void *d_packed, int n, uint8_t *d_yuv, uint8_t *d_rgb, float *ms,
-               int *layout, int *waves, std::string &)
+int stub_h2d(DevCtx *, int n, void *const *dst, const void *const *src, const size_t *bytes, float *ms, std::string &)
+{
+    for (int i = 0; i < n; i++) memcpy(dst[i], src[i], bytes[i]);
+    std::this_thread::sleep_for(std::chrono::microseconds(50));
+    if (ms) *ms = 0.05f;
+    return MVHP_SUCCESS;
+}
+// compact picture -> packed records (the CPU restatement of csrc/hip/expand_compact.hip, for this harness only)
+void expand_compact(const uint8_t *pic, size_t mbs, uint8_t *packed)
+{
+    const uint32_t *off = reinterpret_cast<const uint32_t *>(pic);
+    for (size_t mb = 0; mb < mbs; mb++) {
+        const uint8_t *rec = pic + mbs * 4 + off[mb];
+        uint8_t *out = packed + mb * MVHP_MB_BYTES;
+        memset(out, 0, MVHP_MB_BYTES);
+        memcpy(out, rec, MVHP_MB_HEADER_BYTES);
+        uint32_t n;
+        memcpy(&n, rec + 28, 4);
+        const bool dense = (rec[5] & 1) != 0;
+        out[5] = 0;
+        memset(out + 28, 0, 4);
+        if (dense) { memcpy(out + MVHP_MB_HEADER_BYTES, rec + MVHP_MB_HEADER_BYTES, MVHP_MB_COEFS * 2); continue; }
+        int16_t *coef = reinterpret_cast<int16_t *>(out + MVHP_MB_HEADER_BYTES);
+        for (uint32_t i = 0; i < n; i++) {
+            uint32_t e;
+            memcpy(&e, rec + MVHP_MB_HEADER_BYTES + 4 * i, 4);
+            if ((e & 0xffffu) < (uint32_t)MVHP_MB_COEFS) coef[e & 0xffffu] = (int16_t)(e >> 16);
+        }
+    }
+}
+int stub_recon(DevCtx *, const mvhp_stream_params_t *p, const void *d_compact, size_t stride, void *d_packed, int n, uint8_t *d_yuv,
+               uint8_t *d_rgb, float *ms, int *layout, int *waves, std::string &)
 {
     g_recon_calls++;
     const size_t pb = mvhp_packed_frame_bytes(p), yb = mvhp_yuv_frame_bytes(p), rb = mvhp_rgb_frame_bytes(p);
+    for (int i = 0; i < n; i++)
+        expand_compact((const uint8_t *)d_compact + (size_t)i * stride, (size_t)p->width_mbs * p->height_mbs, (uint8_t *)d_packed + (size_t)i * pb);
     for (int i = 0; i < n; i++) {
         const uint64_t h = checksum((const uint8_t *)d_packed + (size_t)i * pb, pb);
         memset(d_yuv + (size_t)i * yb, 0x5a, yb);
@@ -83,7 +115,7 @@ int stub_recon(DevCtx *, const mvhp_stream_params_t *p, const void *d_packed, in
 }
 
 const mvengine::DeviceApi g_stub = {stub_device_count, stub_host_alloc, stub_host_free, stub_ctx_create, stub_ctx_destroy,
-                                    stub_dev_alloc, stub_dev_free, stub_dev_free_bytes, stub_copy, stub_copy, stub_recon};
+                                    stub_dev_alloc, stub_dev_free, stub_dev_free_bytes, stub_h2d, stub_copy, stub_recon};
 
 struct Check {
     const mvhp_stream *s = nullptr;
