@@ -273,6 +273,10 @@ typedef int (*mvhp_picture_sink_t)(void *user, int seq, int idr, int rc, const c
 
 MVHP_EXPORT int  mvhp_engine_create(const mvhp_engine_opts_t *opts /* may be NULL */, mvhp_engine_t **out);
 MVHP_EXPORT void mvhp_engine_destroy(mvhp_engine_t *e);
+/* `want_rgb` of mvhp_engine_decode: 0 = planes only; MVHP_OUT_RGB = planes and RGB; MVHP_OUT_RGB_ONLY = RGB only (the planes
+ * are still reconstructed on the device -- RGB is made from them -- but not downloaded: the sink gets yuv = NULL). */
+#define MVHP_OUT_RGB      1
+#define MVHP_OUT_RGB_ONLY 3
 /* Decode the pictures order[0..n_order) of `s` (IDR indices) until `wanted` of them have been accepted by the sink
  * (the reference stops after picture_number IDRs, h264.c:173-179: no more pictures than needed are entropy-decoded).
  * sink may be NULL (every reconstructed picture counts as accepted).  Returns MVHP_SUCCESS when `wanted` pictures

@@ -399,7 +399,8 @@ minivideo_EXPORT int minivideo_decode(MediaFile_t *m, const char *output_directo
     sink.picture_number = picture_number;
     mvhp_decode_stats_t st;
     // decodes in order until `wanted` pictures have been written (h264.c:173-179) or 64 errors in a row (h264.c:181-187)
-    (void)mvhp_engine_decode(eng, &s, order.data(), (int)order.size(), wanted, want_rgb ? 1 : 0, ExportSink::call, &sink, &st);
+    // RGB formats are written from the RGB picture alone: the planes stay on the device
+    (void)mvhp_engine_decode(eng, &s, order.data(), (int)order.size(), wanted, want_rgb ? MVHP_OUT_RGB_ONLY : 0, ExportSink::call, &sink, &st);
     mvhp_engine_destroy(eng);
     if (getenv("MINIVIDEO_STATS"))
         fprintf(stderr, "[minivideo] decode: %u pictures entropy-decoded, %u written, %u failed, %u launches (largest %u pictures), "

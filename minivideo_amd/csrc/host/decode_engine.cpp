@@ -173,7 +173,7 @@ public:
     Engine(const DeviceApi &api) : api_(api) {}
     ~Engine();
     bool init(const mvhp_engine_opts_t *opts, std::string &err);
-    int decode(const mvhp_stream &s, const int *order, int n_order, int wanted, bool want_rgb, mvhp_picture_sink_t sink,
+    int decode(const mvhp_stream &s, const int *order, int n_order, int wanted, int out_mask, mvhp_picture_sink_t sink,
                void *user, mvhp_decode_stats_t *stats, std::string &err);
 
 private:
@@ -209,7 +209,7 @@ private:
     const mvhp_stream *s_ = nullptr;
     const int *order_ = nullptr;
     int n_order_ = 0, wanted_ = 0;
-    bool want_rgb_ = false;
+    bool want_rgb_ = false, want_yuv_ = true;   // which outputs are downloaded (the planes are always reconstructed)
     bool stop_ = false;
     bool sink_waiting_ = false;
     int pos_ = 0;                 // next position of `order` the feeder has not issued yet
@@ -720,22 +720,22 @@ void Engine::downloader(int k)
             }
             std::string err;
             float ms = 0.f, ms2 = 0.f;
-            bool ok = grow(oc->yuv, (size_t)C * yb) && (!want_rgb_ || grow(oc->rgb, (size_t)C * rb));
+            bool ok = (!want_yuv_ || grow(oc->yuv, (size_t)C * yb)) && (!want_rgb_ || grow(oc->rgb, (size_t)C * rb));
             if (!ok) err = "out of page-locked host memory";
-            if (ok) ok = api_.d2h(cx.dev, oc->yuv.p, b->buf->yuv + (size_t)g * yb, (size_t)n * yb, &ms, err) == MVHP_SUCCESS;
+            if (ok && want_yuv_) ok = api_.d2h(cx.dev, oc->yuv.p, b->buf->yuv + (size_t)g * yb, (size_t)n * yb, &ms, err) == MVHP_SUCCESS;
             if (ok && want_rgb_) ok = api_.d2h(cx.dev, oc->rgb.p, b->buf->rgb + (size_t)g * rb, (size_t)n * rb, &ms2, err) == MVHP_SUCCESS;
             {
                 std::lock_guard<std::mutex> l(mu_);
                 if (ok) {
                     st_.d2h_s += (ms + ms2) * 1e-3;
-                    st_.d2h_bytes += (uint64_t)n * (yb + rb);
+                    st_.d2h_bytes += (uint64_t)n * ((want_yuv_ ? yb : 0) + rb);
                     oc->refs = 0;
                     for (int i = 0; i < n; i++) {
                         PicResult &r = results_[(size_t)b->seqs[(size_t)(g + i)]];
                         if (!r.parsed_ok || r.ready) continue;
                         r.rc = MVHP_SUCCESS;
                         r.oc = oc;
-                        r.yuv = oc->yuv.p + (size_t)i * yb;
+                        r.yuv = want_yuv_ ? oc->yuv.p + (size_t)i * yb : nullptr;
                         r.rgb = want_rgb_ ? oc->rgb.p + (size_t)i * rb : nullptr;
                         r.ready = true;
                         oc->refs++;
@@ -760,7 +760,7 @@ void Engine::downloader(int k)
 // ---------------------------------------------------------------------------------------------------------------
 // one decode call
 // ---------------------------------------------------------------------------------------------------------------
-int Engine::decode(const mvhp_stream &s, const int *order, int n_order, int wanted, bool want_rgb, mvhp_picture_sink_t sink,
+int Engine::decode(const mvhp_stream &s, const int *order, int n_order, int wanted, int out_mask, mvhp_picture_sink_t sink,
                    void *user, mvhp_decode_stats_t *stats, std::string &err)
 {
     if (!order || n_order <= 0 || wanted <= 0) { err = "nothing to decode"; return MVHP_FAILURE; }
@@ -770,7 +770,9 @@ int Engine::decode(const mvhp_stream &s, const int *order, int n_order, int want
     const int n_ctx = (int)ctx_.size();
     {
         std::lock_guard<std::mutex> l(mu_);
-        s_ = &s; order_ = order; n_order_ = n_order; wanted_ = std::min(wanted, n_order); want_rgb_ = want_rgb;
+        s_ = &s; order_ = order; n_order_ = n_order; wanted_ = std::min(wanted, n_order);
+        want_rgb_ = (out_mask & 1) != 0;
+        want_yuv_ = !want_rgb_ || (out_mask & 2) == 0;
         stop_ = false; sink_waiting_ = false;
         pos_ = issued_ = consumed_ = ok_ = failed_ = 0;
         next_batch_id_ = 0;
@@ -872,11 +874,11 @@ Engine *engine_create(const DeviceApi &api, const mvhp_engine_opts_t *opts, std:
 
 void engine_destroy(Engine *e) { delete e; }
 
-int engine_decode(Engine *e, const mvhp_stream &s, const int *order, int n_order, int wanted, bool want_rgb,
+int engine_decode(Engine *e, const mvhp_stream &s, const int *order, int n_order, int wanted, int out_mask,
                   mvhp_picture_sink_t sink, void *user, mvhp_decode_stats_t *stats, std::string &err)
 {
     if (!e) { err = "no engine"; return MVHP_FAILURE; }
-    return e->decode(s, order, n_order, wanted, want_rgb, sink, user, stats, err);
+    return e->decode(s, order, n_order, wanted, out_mask, sink, user, stats, err);
 }
 
 } // namespace mvengine
@@ -914,7 +916,7 @@ MVHP_EXPORT int mvhp_engine_decode(mvhp_engine_t *h, const mvhp_stream_t *s, con
                                    int want_rgb, mvhp_picture_sink_t sink, void *user, mvhp_decode_stats_t *stats)
 {
     if (!h || !s) return MVHP_FAILURE;
-    const int rc = mvengine::engine_decode(h->e, *s, order, n_order, wanted, want_rgb != 0, sink, user, stats, g_engine_err);
+    const int rc = mvengine::engine_decode(h->e, *s, order, n_order, wanted, want_rgb, sink, user, stats, g_engine_err);
     if (rc != MVHP_SUCCESS) fprintf(stderr, "[minivideo] %s\n", g_engine_err.c_str());
     return rc;
 }

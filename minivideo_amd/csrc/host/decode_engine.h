@@ -44,7 +44,7 @@ class Engine;
 
 Engine *engine_create(const DeviceApi &api, const mvhp_engine_opts_t *opts, std::string &err);
 void    engine_destroy(Engine *e);
-int     engine_decode(Engine *e, const mvhp_stream &s, const int *order, int n_order, int wanted, bool want_rgb,
+int     engine_decode(Engine *e, const mvhp_stream &s, const int *order, int n_order, int wanted, int out_mask,
                       mvhp_picture_sink_t sink, void *user, mvhp_decode_stats_t *stats, std::string &err);
 
 } // namespace mvengine

@@ -263,5 +263,5 @@ class Engine:
 
         cb = SINK_T(_cb) if sink is not None else C.cast(None, SINK_T)
         rc = self._L.mvhp_engine_decode(self._h, stream_handle, order, len(order), len(order) if wanted is None else wanted,
-                                        1 if want_rgb else 0, cb, None, C.byref(st))
+                                        int(want_rgb), cb, None, C.byref(st))   # 0 planes, 1 planes + RGB, 3 RGB only
         return rc, st.as_dict()

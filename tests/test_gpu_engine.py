@@ -198,3 +198,25 @@ def test_expand_kernel_matches_the_packed_records(profile, threshold, monkeypatc
     hot.close()
     got = d_packed.cpu().numpy().reshape(F, W * H, 800)
     assert np.array_equal(got, packed)
+
+
+def test_engine_rgb_only_skips_the_plane_download():
+    """MVHP_OUT_RGB_ONLY (what minivideo_decode asks for when it writes bmp / png / tga): the sink gets RGB and no planes,
+    and only the RGB bytes cross the link"""
+    W, H, F = 12, 8, 20
+    stream, packed = gen.make_stream(W, H, F, seed=93, profile="high")
+    p = StreamParams(W, H, 0, 0, 0)
+    eng = Engine(contexts=1)
+    got = {}
+
+    def sink(seq, idr, rc, err, pr, yuv, rgb):
+        got[seq] = (rc, yuv is None, rgb.copy())
+        return 1
+
+    with Stream(stream) as s:
+        rc, st = eng.decode(s.h, list(range(F)), want_rgb=3, sink=sink)
+    eng.close()
+    assert rc == 1 and st["pictures_ok"] == F and st["d2h_bytes"] == F * p.rgb_bytes
+    for k in range(F):
+        assert got[k][0] == 1 and got[k][1]
+        assert np.array_equal(got[k][2], loader.recon(p, packed[k], 1, want_rgb=True)[1]), k
