@@ -83,6 +83,13 @@ __device__ __forceinline__ int pack_res_shr6(int a, int b)
 
 __device__ __forceinline__ uint32_t lerp_u8(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_lerp(a, b, c); }
 
+#ifndef MVHP_I8_UNROLL
+#define MVHP_I8_UNROLL 4   // the four 8x8 blocks of an Intra8x8 macroblock as four copies: positions become constants (-31 % VALU,
+                           // -78 % SALU in that loop; High 12.64 -> 12.05 ms); 1 = one loop body
+#endif
+#define MVHP_PRAGMA_(x) _Pragma(#x)
+#define MVHP_UNROLL(n) MVHP_PRAGMA_(unroll n)
+
 #ifdef MVHP_MARKS   // measurement builds: section markers that survive into the ISA text (tools/isa_sections.py)
 #define MVHP_MARK(name) asm volatile("; MARK " name ::: "memory")
 #else
@@ -296,11 +303,12 @@ MVHP_MARK("r_8x8");
                     for (int t = 0; t < 4; t++) {
 #pragma unroll
                         for (int c = 0; c < 4; c++) {
-                            const int send = hh ? dr[t][c] : dr[t][c + 4];
-                            const int keep = hh ? dr[t][c + 4] : dr[t][c];
-                            const int recv = dpp_quad<DPP_XOR1>(send);
-                            colv[c][t] = hh ? recv : keep;         // rows 0-3
-                            colv[c][t + 4] = hh ? keep : recv;     // rows 4-7
+                            // rows 0-3: the even lane's own columns 0-3, or (odd lane) the partner's columns 4-7;
+                            // rows 4-7: the partner's columns 0-3 (even lane), or the odd lane's own columns 4-7
+                            // (one select with a DPP operand each)
+                            const int from_lo = dpp_quad<DPP_XOR1>(dr[t][c]), from_hi = dpp_quad<DPP_XOR1>(dr[t][c + 4]);
+                            colv[c][t] = hh ? from_hi : dr[t][c];
+                            colv[c][t + 4] = hh ? dr[t][c + 4] : from_lo;
                         }
                     }
 #pragma unroll
@@ -658,7 +666,7 @@ MVHP_MARK("p_i4_chain");
                 // Intra 8x8: h264_intra_prediction.c:1107-1353 (edge filter) + :1366-1793 + transform8x8_luma;
                 // lane j predicts row j of the block
 MVHP_MARK("p_i8");
-#pragma unroll 1
+                MVHP_UNROLL(MVHP_I8_UNROLL)
                 for (int blk = 0; blk < 4; blk++) {
                     const int bxO = (blk & 1) * 8, byO = (blk >> 1) * 8;
                     const int mode = (int)((m0 >> (blk * 8)) & 255u);
