@@ -29,6 +29,13 @@
 
 namespace mvhp {
 
+#ifndef MVHP_I8_UNROLL
+#define MVHP_I8_UNROLL 4   // the four 8x8 blocks of an Intra8x8 macroblock as four copies (positions become constants: 2160p High
+                           // 26.08 -> 24.82 ms, 1080p High 13.70 -> 13.54 ms); 1 = one loop body
+#endif
+#define MVHP_PRAGMA_(x) _Pragma(#x)
+#define MVHP_UNROLL(n) MVHP_PRAGMA_(unroll n)
+
 #ifndef MVHP_CHAIN_PRIO
 #define MVHP_CHAIN_PRIO 2   // wave priority inside the Intra4x4 chain
 #endif
@@ -558,7 +565,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_num_vgpr(100))) void
             } else {
                 // Intra 8x8: h264_intra_prediction.c:1107-1353 (edge filter) + :1366-1793 + transform8x8_luma;
                 // lane j predicts samples (4*(j&1) .. +3, j>>1) of the block
-#pragma unroll 1
+                MVHP_UNROLL(MVHP_I8_UNROLL)
                 for (int blk = 0; blk < 4; blk++) {
                     const int bxO = (blk & 1) * 8, byO = (blk >> 1) * 8;
                     const int mode = (int)((m0 >> (blk * 8)) & 255u);
