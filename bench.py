@@ -61,7 +61,7 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=5.0, help="budget of each of the four CPU baseline legs")
     ap.add_argument("--e2e-pictures", type=int, default=-1,
-                    help="pictures of the end-to-end leg, in total over the ranks (-1: 2048 = two launches of the four-picture kernel, or P with --strong; 0: skip)")
+                    help="pictures of the end-to-end leg, in total over the ranks (-1: 2048 per rank, or P with --strong; 0: skip)")
     ap.add_argument("--e2e-batch", type=int, default=0, help="pictures per launch in the end-to-end leg (0: engine default)")
     ap.add_argument("--host-threads", type=int, default=0, help="entropy threads per rank (0: host cores / ranks)")
     return ap.parse_args()
@@ -214,12 +214,13 @@ def end_to_end(args, params, stream, n_distinct, rec, want_rgb, total, rank, wor
     L = lib()
     cores = host_cores()
     threads = args.host_threads or max(1, cores // world)
-    big = repeat_stream(stream, n_distinct, total)
-    h = C.c_void_p()
-    if L.mvhp_stream_open(big.ctypes.data, big.size, C.byref(h)) != 1 or L.mvhp_stream_idr_count(h) != total:
-        raise SystemExit("bench: the end-to-end stream failed to parse")
     lo, hi = shard(total, rank, world)
-    order = list(range(lo, hi))
+    mine = hi - lo                           # every rank builds and decodes its own share of the pictures
+    big = repeat_stream(stream, n_distinct, mine)
+    h = C.c_void_p()
+    if L.mvhp_stream_open(big.ctypes.data, big.size, C.byref(h)) != 1 or L.mvhp_stream_idr_count(h) != mine:
+        raise SystemExit("bench: the end-to-end stream failed to parse")
+    order = list(range(mine))
     eng = Engine(contexts=1, host_threads=threads, batch_pictures=args.e2e_batch, first_device=local_rank)
     check = sorted({0, 1, len(order) // 2, len(order) - 1} & set(range(len(order))))
     kept = {}
@@ -433,7 +434,8 @@ def main():
     torch.cuda.empty_cache()
 
     # ---- end to end (stream bytes -> host planes), every rank on its share ----
-    e2e_total = args.e2e_pictures if args.e2e_pictures >= 0 else (args.strong or 2048)
+    # like the kernel leg: weak scaling by default (2048 pictures per rank), the fixed job with --strong
+    e2e_total = args.e2e_pictures if args.e2e_pictures >= 0 else (args.strong or 2048 * world)
     e2e = None
     if e2e_total >= world and stream is not None:
         e2e = end_to_end(args, params, stream, n_distinct, rec, want_rgb, e2e_total, rank, world, local_rank, dist, dev)
