@@ -1,5 +1,9 @@
 #!/bin/bash
 # Memory-path counters (TA / TCP / TCC / EA) for the bench workload.
+# CAUTION (round 2): on ROCm 7.2 / gfx950 the first pass of this script made rocprofv3 abort (signal 6 inside the profiled
+# process) and the run then sat silent until the job limit -- 8 GPU-minutes for nothing.  Run it under `timeout -k 10 300`
+# and one counter group at a time if it is needed again; FETCH_SIZE / WRITE_SIZE / SQ_* (tools/profile_config.sh,
+# tools/pmc_profile2.sh) work.
 # usage (on the GPU box, from the repo root): bash tools/pmc_mem.sh <tag> [bench args...]
 set -e
 TAG=$1; shift
