@@ -12,14 +12,14 @@ namespace h264 {
 
 static inline int clip3(int lo, int hi, int v) { return v < lo ? lo : (v > hi ? hi : v); }
 
-uint8_t CabacEngine::kNextMps[128], CabacEngine::kNextLps[128], CabacEngine::kRangeLpsQ[64][4];
+uint8_t CabacEngine::kNext[256], CabacEngine::kRangeLpsQ[64][4];
 
 void CabacEngine::build_tables()
 {
     for (int st = 0; st < 64; st++) {
         for (int mps = 0; mps < 2; mps++) {
-            kNextMps[st * 2 + mps] = (uint8_t)(kTransMps[st] * 2 + mps);
-            kNextLps[st * 2 + mps] = (uint8_t)(kTransLps[st] * 2 + (st == 0 ? 1 - mps : mps));   // valMPS flips at state 0
+            kNext[(st * 2 + mps) * 2 + 0] = (uint8_t)(kTransMps[st] * 2 + mps);
+            kNext[(st * 2 + mps) * 2 + 1] = (uint8_t)(kTransLps[st] * 2 + (st == 0 ? 1 - mps : mps));   // valMPS flips at state 0
         }
         for (int q = 0; q < 4; q++) kRangeLpsQ[st][q] = kRangeLps[q][st];
     }

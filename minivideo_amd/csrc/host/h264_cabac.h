@@ -34,33 +34,29 @@ struct CabacEngine {
     // comparison, renormalisation only lowers k_, and the bit reader is asked for 32 bits at a time.
     int decode_decision(int ctx)
     {
+        // branch-free on the bin value (about half of all bins are not predictable): the LPS case is folded in with a mask
         const uint32_t st = st_[ctx];
         const uint32_t lps = kRangeLpsQ[st >> 1][(range_ >> 6) & 3];
-        range_ -= lps;
-        const uint64_t scaled = (uint64_t)range_ << k_;
-        int bin = (int)(st & 1u);
-        if (val_ >= scaled) {
-            val_ -= scaled;
-            range_ = lps;
-            bin ^= 1;
-            st_[ctx] = kNextLps[st];
-        } else {
-            st_[ctx] = kNextMps[st];
-        }
-        if (range_ < 256) {
-            const int sh = __builtin_clz(range_) - 23;
-            range_ <<= sh;
-            k_ -= sh;
-            if (k_ < 16) refill();
-        }
+        const uint32_t rmps = range_ - lps;
+        const uint64_t scaled = (uint64_t)rmps << k_;
+        const uint64_t is_lps = (uint64_t)0 - (uint64_t)(val_ >= scaled);   // all ones when the LPS was coded
+        val_ -= scaled & is_lps;
+        uint32_t range = (uint32_t)((rmps & ~is_lps) | (lps & is_lps));
+        st_[ctx] = kNext[(st << 1) | (uint32_t)(is_lps & 1u)];
+        const int bin = (int)((st ^ (uint32_t)is_lps) & 1u);
+        const int sh = __builtin_clz(range) - 23;   // 0 while range >= 256 (range < 512 always)
+        range_ = range << sh;
+        k_ -= sh;
+        if (k_ < 16) refill();
         return bin;
     }
     int decode_bypass()
     {
         if (--k_ < 16) refill();
         const uint64_t scaled = (uint64_t)range_ << k_;
-        if (val_ >= scaled) { val_ -= scaled; return 1; }
-        return 0;
+        const uint64_t one = (uint64_t)0 - (uint64_t)(val_ >= scaled);   // sign bits are coin flips: no branch on them
+        val_ -= scaled & one;
+        return (int)(one & 1u);
     }
     int decode_terminate()
     {
@@ -93,7 +89,7 @@ private:
     uint64_t val_ = 0;
     int      k_ = 0;
     // transitions on the combined state byte, rangeTabLPS as [state][quarter]: built once from Tables 9-44 / 9-45
-    static uint8_t kNextMps[128], kNextLps[128], kRangeLpsQ[64][4];
+    static uint8_t kNext[256], kRangeLpsQ[64][4];   // kNext[state byte << 1 | LPS coded]
     static void build_tables();
 public:
     static void build_tables_once();
