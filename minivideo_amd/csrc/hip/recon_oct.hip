@@ -28,6 +28,9 @@ namespace mvhp {
 #ifndef MVHP_LOAD_HINT
 #define MVHP_LOAD_HINT ""   // cache-policy suffix of the record loads (measurement builds try " nt")
 #endif
+#ifndef MVHP_STORE_HINT
+#define MVHP_STORE_HINT ""  // the same for the strip stores
+#endif
 // The eight-picture kernel's LDS block per picture and wave: QLds (recon_batch_device.h) with the filtered Intra8x8
 // edge kept as three 28-entry arrays -- G[0][k] = p'[k] (the unified edge EE of recon_device.h mode_entry(): 0-1 left[7]
 // replicated, 2-9 left[7..0], 10 corner, 11-26 top[0..15], 27 top[15] replicated), G[1][k] = (p'[k] + p'[k+1] + 1) >> 1,
@@ -44,7 +47,7 @@ struct __attribute__((aligned(16))) OLds {
     uint8_t G[3][32];        // Intra8x8: filtered edge arrays of the block being predicted
     uint8_t Lc8[8];          // Intra8x8: right column of 8x8 block 0 / 2 = left neighbours of block 1 / 3
     uint8_t pad8[8];
-    uint8_t SC[2][8 * 24];   // output strip, chroma rows of the three parked macroblocks
+    uint8_t SC[2][8 * 24];   // output strip: [plane][chroma row][parked macroblock 0..2] x 8 bytes
 #ifdef MVHP_OLDS_PAD
     uint8_t pad[MVHP_OLDS_PAD];   // measurement builds: bank offset between the pictures of a wavefront
 #endif
@@ -155,13 +158,7 @@ __global__ __launch_bounds__(NW * 64) void recon_oct_kernel(ReconArgs a)
 
     // Record prefetch, one macroblock ahead, in v216-v247: header (32 B), the lane's two luma blocks (64 B), its
     // chroma block (32 B).  A step issues no store or exactly VM_STRIP stores behind the eight loads (`n_st`).
-#if defined(MVHP_ABL_NO_YUV_STORE)
-    constexpr int VM_STRIP = 0;
-#elif defined(MVHP_ABL_NO_RGB_STORE)
-    constexpr int VM_STRIP = 12;
-#else
-    constexpr int VM_STRIP = RGB ? 36 : 12;   // a full strip: 2 rows x 4 luma + 2 x 2 chroma (+ 2 x 12 RGB) 16-byte stores
-#endif
+    constexpr int VM_STRIP = 16 + (RGB ? 24 : 0);   // a full strip: 8 luma rows + 4 chroma rows x 2 planes (+ 8 rows x 3 RGB pieces)
     auto prefetch = [&](int prow, int px, int lane_p) {
         const int jj = lane_p & 7;
         uint32_t qmb_v = qmb;
@@ -193,8 +190,8 @@ __global__ __launch_bounds__(NW * 64) void recon_oct_kernel(ReconArgs a)
     const int up_adj = __builtin_amdgcn_readfirstlane((wave == 0) ? -1 : 0); // wave 0 follows the last wave's previous pass
     int done = 0;  // macroblocks completed by this wave
     int n_st = 0;  // asm stores the previous step issued behind its prefetch (0 also when the compiler counted them)
-    // output strip: luma rows 2j and 2j+1 of three parked macroblocks (registers); their chroma rows live in LDS (Q.SC)
-    v4i st_a0 = {0, 0, 0, 0}, st_a1 = st_a0, st_a2 = st_a0, st_b0 = st_a0, st_b1 = st_a0, st_b2 = st_a0;
+    // output strip (see the write-out): the luma rows this lane owns of "its" macroblock of the strip; chroma rows wait in LDS (Q.SC)
+    v4i L0 = {0, 0, 0, 0}, L1 = L0, L2 = L0, L3 = L0, L4 = L0, L5 = L0, L6 = L0, L7 = L0;
 
     for (int row = wave; row < H; row += NW) {
         const int pass = row / NW;
@@ -767,109 +764,112 @@ MVHP_MARK("p_i8");
             // planes -- the chroma row those two luma rows share (export_utils.c:278-279), so its colour terms are
             // computed once; park, or flush the 4-macroblock strip
             // =====================================================================================
+            // Strip ownership by MACROBLOCK: lane (m, h) = (j & 3, j >> 2) of an octet keeps, of macroblock m of the 4-macroblock
+            // strip, luma rows 4i + 2h, 4i + 2h + 1 (i < 4) -- pairs that share chroma row 2i + h -- and writes them when the
+            // strip is complete: in one store instruction lanes m = 0..3 then cover 64 contiguous bytes of a luma row
+            // (32 of a chroma row), and the 192 RGB bytes of a row leave in three consecutive instructions.
             MVHP_MARK("writeout");
             {
                 const int mbi = mbx & 3;
-                const uint4 ya = *reinterpret_cast<const uint4 *>(&Q.T[(2 * j + 1) * 32 + 16]);   // luma row 2j
-                const uint4 yb = *reinterpret_cast<const uint4 *>(&Q.T[(2 * j + 2) * 32 + 16]);   // luma row 2j + 1
-                const uint2 cvb = *reinterpret_cast<const uint2 *>(&Q.TC[0][(j + 1) * 16 + 8]);   // chroma row j: the row of
-                const uint2 cvr = *reinterpret_cast<const uint2 *>(&Q.TC[1][(j + 1) * 16 + 8]);   // both luma rows
-                const v4i yqa = {(int)ya.x, (int)ya.y, (int)ya.z, (int)ya.w}, yqb = {(int)yb.x, (int)yb.y, (int)yb.z, (int)yb.w};
+                const int m_own = j & 3, h_own = j >> 2;
                 n_st = 0;
+                if (m_own == mbi) {   // this macroblock's owners take its luma rows out of the tile
+                    const uint8_t *t0 = &Q.T[(2 * h_own + 1) * 32 + 16];
+                    L0 = *reinterpret_cast<const v4i *>(t0);            L1 = *reinterpret_cast<const v4i *>(t0 + 32);
+                    L2 = *reinterpret_cast<const v4i *>(t0 + 4 * 32);   L3 = *reinterpret_cast<const v4i *>(t0 + 5 * 32);
+                    L4 = *reinterpret_cast<const v4i *>(t0 + 8 * 32);   L5 = *reinterpret_cast<const v4i *>(t0 + 9 * 32);
+                    L6 = *reinterpret_cast<const v4i *>(t0 + 12 * 32);  L7 = *reinterpret_cast<const v4i *>(t0 + 13 * 32);
+                }
                 if (mbi == 3 || mbx == W - 1) {
                     uint32_t qmb_v = qmb;
                     asm volatile("" : "+v"(qmb_v));
-                    const uint32_t oyuv = OYUV;
-                    const uint32_t lrow = (uint32_t)((row * 16 + 2 * j) * pitch + (mbx & ~3) * 16);   // luma row 2j, inside the plane
-                    const uint32_t pya = oyuv + lrow, pyb = pya + pitch;
-                    const uint32_t pcb = oyuv + plane_y + (uint32_t)((row * 8 + j) * cpitch + (mbx & ~3) * 8), pcr = pcb + plane_c;
-                    const uint32_t prgba = ORGB + lrow * 3u, prgbb = prgba + 3 * pitch;
-                    const uint2 *ownb = reinterpret_cast<const uint2 *>(&Q.SC[0][j * 24]);   // parked: this lane's chroma rows
-                    const uint2 *ownr = reinterpret_cast<const uint2 *>(&Q.SC[1][j * 24]);
-MVHP_MARK("w_full");
+                    // chroma rows 2i + h of the lane's macroblock: parked ones from the strip, the current one from the tile
+                    const bool cur = (m_own == mbi);
+                    const uint8_t *cb_src = cur ? &Q.TC[0][(h_own + 1) * 16 + 8] : &Q.SC[0][h_own * 24 + m_own * 8];
+                    const uint8_t *cr_src = cur ? &Q.TC[1][(h_own + 1) * 16 + 8] : &Q.SC[1][h_own * 24 + m_own * 8];
+                    const int cstep = cur ? 32 : 48;
+                    const uint2 cb0 = *reinterpret_cast<const uint2 *>(cb_src), cb1 = *reinterpret_cast<const uint2 *>(cb_src + cstep);
+                    const uint2 cb2 = *reinterpret_cast<const uint2 *>(cb_src + 2 * cstep), cb3 = *reinterpret_cast<const uint2 *>(cb_src + 3 * cstep);
+                    const uint2 cr0 = *reinterpret_cast<const uint2 *>(cr_src), cr1 = *reinterpret_cast<const uint2 *>(cr_src + cstep);
+                    const uint2 cr2 = *reinterpret_cast<const uint2 *>(cr_src + 2 * cstep), cr3 = *reinterpret_cast<const uint2 *>(cr_src + 3 * cstep);
+                    const uint32_t x0 = (uint32_t)((mbx & ~3) * 16 + m_own * 16);
+                    const uint32_t lrow = (uint32_t)((row * 16 + 2 * h_own) * pitch) + x0;     // luma row 2h of the macroblock row
+                    const uint32_t pl = OYUV + lrow;
+                    const uint32_t pcb = OYUV + plane_y + (uint32_t)((row * 8 + h_own) * cpitch) + (x0 >> 1), pcr = pcb + plane_c;
+                    const uint32_t p4 = 4u * (uint32_t)pitch, c2 = 2u * (uint32_t)cpitch;
                     if (mbi == 3) {
                         // ---- full strip: exactly VM_STRIP store instructions ----
-                        const uint2 b0 = ownb[0], b1 = ownb[1], b2 = ownb[2], q0 = ownr[0], q1 = ownr[1], q2 = ownr[2];
-                        const v4i cb01 = {(int)b0.x, (int)b0.y, (int)b1.x, (int)b1.y}, cb23 = {(int)b2.x, (int)b2.y, (int)cvb.x, (int)cvb.y};
-                        const v4i cr01 = {(int)q0.x, (int)q0.y, (int)q1.x, (int)q1.y}, cr23 = {(int)q2.x, (int)q2.y, (int)cvr.x, (int)cvr.y};
-#define MVHP_ST(ADDR, DATA, BASE, OFF) asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 offset:" #OFF "\n\ts_nop 1" : : "v"(ADDR), "v"(DATA), "s"(BASE) : "memory")
-#if defined(MVHP_ABL_NO_YUV_STORE)
-                        if (valid && a.n_frames < 0) {
-#else
+#define MVHP_ST(ADDR, DATA, BASE, OFF) MVHP_ST_(ADDR, DATA, BASE, OFF)
+#define MVHP_ST_(ADDR, DATA, BASE, OFF) asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 offset:" #OFF MVHP_STORE_HINT "\n\ts_nop 1" : : "v"(ADDR), "v"(DATA), "s"(BASE) : "memory")
+#define MVHP_ST2(ADDR, DATA, BASE) asm volatile("s_nop 4\n\tglobal_store_dwordx2 %0, %1, %2" MVHP_STORE_HINT : : "v"(ADDR), "v"(DATA), "s"(BASE) : "memory")
                         if (valid) {
-#endif
-                            MVHP_ST(pya, st_a0, gyuv, 0); MVHP_ST(pya, st_a1, gyuv, 16); MVHP_ST(pya, st_a2, gyuv, 32); MVHP_ST(pya, yqa, gyuv, 48);
-                            MVHP_ST(pyb, st_b0, gyuv, 0); MVHP_ST(pyb, st_b1, gyuv, 16); MVHP_ST(pyb, st_b2, gyuv, 32); MVHP_ST(pyb, yqb, gyuv, 48);
-                            MVHP_ST(pcb, cb01, gyuv, 0); MVHP_ST(pcb, cb23, gyuv, 16);
-                            MVHP_ST(pcr, cr01, gyuv, 0); MVHP_ST(pcr, cr23, gyuv, 16);
+                            MVHP_ST(pl, L0, gyuv, 0);            MVHP_ST(pl + pitch, L1, gyuv, 0);
+                            MVHP_ST(pl + p4, L2, gyuv, 0);       MVHP_ST(pl + p4 + pitch, L3, gyuv, 0);
+                            MVHP_ST(pl + 2 * p4, L4, gyuv, 0);   MVHP_ST(pl + 2 * p4 + pitch, L5, gyuv, 0);
+                            MVHP_ST(pl + 3 * p4, L6, gyuv, 0);   MVHP_ST(pl + 3 * p4 + pitch, L7, gyuv, 0);
+                            const v2i b0 = {(int)cb0.x, (int)cb0.y}, b1 = {(int)cb1.x, (int)cb1.y}, b2 = {(int)cb2.x, (int)cb2.y}, b3 = {(int)cb3.x, (int)cb3.y};
+                            const v2i q0 = {(int)cr0.x, (int)cr0.y}, q1 = {(int)cr1.x, (int)cr1.y}, q2 = {(int)cr2.x, (int)cr2.y}, q3 = {(int)cr3.x, (int)cr3.y};
+                            MVHP_ST2(pcb, b0, gyuv);            MVHP_ST2(pcr, q0, gyuv);
+                            MVHP_ST2(pcb + c2, b1, gyuv);       MVHP_ST2(pcr + c2, q1, gyuv);
+                            MVHP_ST2(pcb + 2 * c2, b2, gyuv);   MVHP_ST2(pcr + 2 * c2, q2, gyuv);
+                            MVHP_ST2(pcb + 3 * c2, b3, gyuv);   MVHP_ST2(pcr + 3 * c2, q3, gyuv);
                         }
                         if (RGB) {
-#if defined(MVHP_ABL_NO_RGB_STORE)
-#define MVHP_RGB_STORE_COND false
-#else
-#define MVHP_RGB_STORE_COND valid
-#endif
-                            // one macroblock of the strip: both luma rows against the chroma row they share
-#define MVHP_RGB_OUT(YQA, YQB, CB, CR, OFF)                                                                            \
+                            const uint32_t prgb = ORGB + lrow * 3u;
+                            // a row pair of the lane's macroblock against the chroma row it shares (export_utils.c:278-279)
+#define MVHP_RGB_OUT(YQA, YQB, CB, CR, I)                                                                              \
                             {                                                                                          \
                                 v4i a0, a1, a2, c0, c1, c2;                                                            \
                                 rgb16x2(make_uint4((uint32_t)(YQA).x, (uint32_t)(YQA).y, (uint32_t)(YQA).z, (uint32_t)(YQA).w), \
                                         make_uint4((uint32_t)(YQB).x, (uint32_t)(YQB).y, (uint32_t)(YQB).z, (uint32_t)(YQB).w), \
                                         CB, CR, a0, a1, a2, c0, c1, c2);                                               \
-                                if (MVHP_RGB_STORE_COND) {                                                             \
-                                    MVHP_ST(prgba, a0, grgb, OFF); MVHP_ST(prgba, a1, grgb, OFF + 16); MVHP_ST(prgba, a2, grgb, OFF + 32); \
-                                    MVHP_ST(prgbb, c0, grgb, OFF); MVHP_ST(prgbb, c1, grgb, OFF + 16); MVHP_ST(prgbb, c2, grgb, OFF + 32); \
+                                const uint32_t pa = prgb + (I) * 3u * p4, pb = pa + 3u * (uint32_t)pitch;               \
+                                if (valid) {                                                                           \
+                                    MVHP_ST(pa, a0, grgb, 0); MVHP_ST(pa, a1, grgb, 16); MVHP_ST(pa, a2, grgb, 32);     \
+                                    MVHP_ST(pb, c0, grgb, 0); MVHP_ST(pb, c1, grgb, 16); MVHP_ST(pb, c2, grgb, 32);     \
                                 } else {                                                                               \
                                     asm volatile("" : : "v"(a0), "v"(a1), "v"(a2), "v"(c0), "v"(c1), "v"(c2));         \
                                 }                                                                                      \
                             }
-                            MVHP_RGB_OUT(st_a0, st_b0, b0, q0, 0)
-                            MVHP_RGB_OUT(st_a1, st_b1, b1, q1, 48)
-                            MVHP_RGB_OUT(st_a2, st_b2, b2, q2, 96)
-                            MVHP_RGB_OUT(yqa, yqb, cvb, cvr, 144)
+                            MVHP_RGB_OUT(L0, L1, cb0, cr0, 0u)
+                            MVHP_RGB_OUT(L2, L3, cb1, cr1, 1u)
+                            MVHP_RGB_OUT(L4, L5, cb2, cr2, 2u)
+                            MVHP_RGB_OUT(L6, L7, cb3, cr3, 3u)
 #undef MVHP_RGB_OUT
-#undef MVHP_RGB_STORE_COND
                         }
 #undef MVHP_ST
+#undef MVHP_ST_
+#undef MVHP_ST2
                         n_st = VM_STRIP;
-                    } else {
+                    } else if (m_own <= mbi && valid) {
                         // ---- short strip at the right picture edge (W % 4 != 0): compiler-counted stores ----
+                        const v4i Lr[8] = {L0, L1, L2, L3, L4, L5, L6, L7};
+                        const uint2 cbr[4] = {cb0, cb1, cb2, cb3}, crr[4] = {cr0, cr1, cr2, cr3};
 #pragma unroll
-                        for (int k = 0; k < 3; k++) {
-                            if (k > mbi) continue;
-                            const bool last = (k == mbi);
-                            const v4i yka = last ? yqa : (k == 0 ? st_a0 : st_a1), ykb = last ? yqb : (k == 0 ? st_b0 : st_b1);
-                            const uint2 ob = ownb[k], orr = ownr[k];   // read first, then choose values
-                            uint2 ckb, ckr;
-                            ckb.x = last ? cvb.x : ob.x; ckb.y = last ? cvb.y : ob.y;
-                            ckr.x = last ? cvr.x : orr.x; ckr.y = last ? cvr.y : orr.y;
-                            if (valid) {
-                                *reinterpret_cast<v4i *>(gyuv + pya + k * 16) = yka;
-                                *reinterpret_cast<v4i *>(gyuv + pyb + k * 16) = ykb;
-                                *reinterpret_cast<uint2 *>(gyuv + pcb + k * 8) = ckb;
-                                *reinterpret_cast<uint2 *>(gyuv + pcr + k * 8) = ckr;
-                            }
+                        for (int i = 0; i < 4; i++) {
+                            *reinterpret_cast<v4i *>(gyuv + pl + i * p4) = Lr[2 * i];
+                            *reinterpret_cast<v4i *>(gyuv + pl + i * p4 + pitch) = Lr[2 * i + 1];
+                            *reinterpret_cast<uint2 *>(gyuv + pcb + i * c2) = cbr[i];
+                            *reinterpret_cast<uint2 *>(gyuv + pcr + i * c2) = crr[i];
                             if (RGB) {
-                                v4i a0, a1, a2, c0, c1, c2;
-                                rgb16x2(make_uint4((uint32_t)yka.x, (uint32_t)yka.y, (uint32_t)yka.z, (uint32_t)yka.w),
-                                        make_uint4((uint32_t)ykb.x, (uint32_t)ykb.y, (uint32_t)ykb.z, (uint32_t)ykb.w), ckb, ckr, a0, a1, a2, c0, c1, c2);
-                                if (valid) {
-                                    v4i *dst = reinterpret_cast<v4i *>(grgb + prgba + k * 48);
-                                    dst[0] = a0; dst[1] = a1; dst[2] = a2;
-                                    dst = reinterpret_cast<v4i *>(grgb + prgbb + k * 48);
-                                    dst[0] = c0; dst[1] = c1; dst[2] = c2;
-                                }
+                                v4i a0, a1, a2, c0, c1, c2v;
+                                rgb16x2(make_uint4((uint32_t)Lr[2 * i].x, (uint32_t)Lr[2 * i].y, (uint32_t)Lr[2 * i].z, (uint32_t)Lr[2 * i].w),
+                                        make_uint4((uint32_t)Lr[2 * i + 1].x, (uint32_t)Lr[2 * i + 1].y, (uint32_t)Lr[2 * i + 1].z, (uint32_t)Lr[2 * i + 1].w),
+                                        cbr[i], crr[i], a0, a1, a2, c0, c1, c2v);
+                                const uint32_t prgb = ORGB + lrow * 3u;
+                                v4i *dst = reinterpret_cast<v4i *>(grgb + prgb + i * 3u * p4);
+                                dst[0] = a0; dst[1] = a1; dst[2] = a2;
+                                dst = reinterpret_cast<v4i *>(grgb + prgb + i * 3u * p4 + 3u * (uint32_t)pitch);
+                                dst[0] = c0; dst[1] = c1; dst[2] = c2v;
                             }
                         }
                     }
                 } else {
-MVHP_MARK("w_park");
-                    // ---- park: luma rows in registers, chroma rows in the LDS strip ----
+                    // ---- park the chroma rows (lane j: row j of both planes) in the LDS strip ----
+                    const uint2 cvb = *reinterpret_cast<const uint2 *>(&Q.TC[0][(j + 1) * 16 + 8]);
+                    const uint2 cvr = *reinterpret_cast<const uint2 *>(&Q.TC[1][(j + 1) * 16 + 8]);
                     *reinterpret_cast<uint2 *>(&Q.SC[0][j * 24 + mbi * 8]) = cvb;
                     *reinterpret_cast<uint2 *>(&Q.SC[1][j * 24 + mbi * 8]) = cvr;
-                    if (mbi == 0) { st_a0 = yqa; st_b0 = yqb; }
-                    else if (mbi == 1) { st_a1 = yqa; st_b1 = yqb; }
-                    else { st_a2 = yqa; st_b2 = yqb; }
                 }
             }
 

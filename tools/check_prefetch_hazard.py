@@ -11,6 +11,7 @@ fault) -- and >= 2 wait states (`s_nop 1`) behind a 128-bit store b
 The oct kernel's prefetch registers are v216-v247.
 Violations raise HazardError (never a bare assert: the check must survive `python -O`).
 usage: check_prefetch_hazard.py file.s"""
+import os
 import re
 import sys
 
@@ -36,7 +37,7 @@ def regs(tok):
 # kernel family -> (prefetch registers, asm loads per prefetch block, stores of a full strip without / with RGB)
 FAMILIES = {
     "recon_quad_kernel": (set(range(100, 124)), 6, (6, 18)),
-    "recon_oct_kernel": (set(range(216, 248)), 8, (12, 36)),
+    "recon_oct_kernel": (set(range(216, 248)), 8, (16, 40)),
 }
 
 
@@ -44,6 +45,9 @@ def check(L, name):
     """L = the lines of one kernel."""
     fam = next(v for k, v in FAMILIES.items() if k in name)
     PREFETCH, n_block, strip_counts = fam
+    # measurement builds that leave stores out (tools/build_variant.sh -DMVHP_ABL_*) name their own counts
+    if os.environ.get("MVHP_CHECK_STRIP_COUNTS"):
+        strip_counts = tuple(int(v) for v in os.environ["MVHP_CHECK_STRIP_COUNTS"].split(","))
     first = "v[%d:%d]" % (min(PREFETCH), min(PREFETCH) + 1)
     in_asm, touched, asm_loads, asm_stores_at = False, [], [], []
     for i, raw in enumerate(L):
@@ -116,7 +120,8 @@ def check(L, name):
     spills = [i for i in range(labi, max(back) + 1) if re.match(r'\s+scratch_', L[i])]
     require(not spills, name, 'scratch access inside the macroblock loop', spills[:3])
     in_loop = [i for i in asm_stores_at if labi <= i <= max(back)]
-    require(len(in_loop) == len(asm_stores_at) == n_expect, name, len(in_loop), len(asm_stores_at), n_expect)
+    if not os.environ.get("MVHP_CHECK_STRIP_COUNTS"):   # (measurement builds keep unreachable stores behind a false condition)
+        require(len(in_loop) == len(asm_stores_at) == n_expect, name, len(in_loop), len(asm_stores_at), n_expect)
     return n_expect, len(asm_loads)
 
 
