@@ -108,11 +108,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_num_vgpr(100))) void
     // (v_readlane, a VALU write of an SGPR) by the instruction right in front of it, and a vector-memory read of such
     // an SGPR needs that distance.  Each asm store also carries two wait states behind it: a VALU write of the data registers of a >64-bit store right behind it
     // is a hardware hazard the compiler cannot see through inline assembly.
-#if defined(MVHP_ABL_NO_RGB_STORE)
-    constexpr int VM_STRIP = 6;               // measurement build: RGB computed, not stored
-#else
-    constexpr int VM_STRIP = RGB ? 18 : 6;    // a full strip: 4 luma + 2 chroma (+ 12 RGB) 16-byte stores per lane
-#endif
+    constexpr int VM_STRIP = 8 + (RGB ? 12 : 0);   // a full strip per lane: 4 luma rows (16 B) + 2 chroma rows x 2 planes (8 B) (+ 4 rows x 3 RGB pieces)
     auto prefetch = [&](int prow, int px, int lane_p) {
         const int jj = lane_p & 15;
         uint32_t qmb_v = qmb;
@@ -137,12 +133,13 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_num_vgpr(100))) void
     const int up_adj = __builtin_amdgcn_readfirstlane((wave == 0) ? -1 : 0); // wave 0 follows the last wave's previous pass
     int done = 0; // macroblocks completed by this wave
     int n_st = 0;  // asm stores the previous step issued after its prefetch (0 also when the compiler counted them)
-    // Output strip: lane j parks luma row j (16 B, registers) and chroma row j & 7 of plane j >> 3 (8 B, LDS) of three
-    // macroblocks; the fourth one triggers the flush:
-    // 64 bytes of luma, 32 of chroma and 192 of RGB per lane, contiguous (HBM likes long runs: with 16-byte runs the
-    // write traffic doubled, with 32-byte runs the writes alone cost 40 % of the kernel).
-    v4i st_y0 = {0, 0, 0, 0}, st_y1 = st_y0, st_y2 = st_y0;
-    // (the parked chroma rows live in LDS, Q.SC: both the lane's own row and the rows the RGB conversion needs)
+    // Output strip, owned by MACROBLOCK (as recon_oct.hip): lane (m, h) = (j & 3, j >> 2) of a quarter keeps luma rows
+    // 4h .. 4h+3 of macroblock m of the 4-macroblock strip (two row pairs, each sharing a chroma row) and writes them when
+    // the strip is complete: four adjacent lanes then cover 64 contiguous bytes of a luma row (32 of a chroma row) per store
+    // instruction, and the 192 RGB bytes of a row leave in three consecutive instructions.  (HBM likes long runs, and L2
+    // lines that are completed piecemeal leave early: with 16-byte runs the write traffic doubled.)  The chroma rows of the
+    // three parked macroblocks wait in LDS (Q.SC).
+    v4i L0 = {0, 0, 0, 0}, L1 = L0, L2 = L0, L3 = L0;
     for (int row = wave; row < H; row += NW) {
         const int pass = row / NW;
         // MBs the upper wave finished before its row (row-1); kept scalar explicitly
@@ -648,105 +645,91 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_num_vgpr(100))) void
             // =====================================================================================
             {
                 const int mbi = mbx & 3;
-                const uint4 yv = *reinterpret_cast<const uint4 *>(&Q.T[(j + 1) * 32 + 16]);
-                const uint2 cv = *reinterpret_cast<const uint2 *>(&Q.TC[j >> 3][((j & 7) + 1) * 16 + 8]);
-                uint2 cbv = make_uint2(0u, 0u), crv = cbv;
-                if (RGB) {
-                    cbv = *reinterpret_cast<const uint2 *>(&Q.TC[0][((j >> 1) + 1) * 16 + 8]);
-                    crv = *reinterpret_cast<const uint2 *>(&Q.TC[1][((j >> 1) + 1) * 16 + 8]);
-                }
-                const v4i yq = {(int)yv.x, (int)yv.y, (int)yv.z, (int)yv.w};
-                const v2i cq = {(int)cv.x, (int)cv.y};
+                const int m_own = j & 3, h_own = j >> 2;
                 n_st = 0;
+                if (m_own == mbi) {   // this macroblock's owners take its luma rows out of the tile
+                    const uint8_t *t0 = &Q.T[(4 * h_own + 1) * 32 + 16];
+                    L0 = *reinterpret_cast<const v4i *>(t0);            L1 = *reinterpret_cast<const v4i *>(t0 + 32);
+                    L2 = *reinterpret_cast<const v4i *>(t0 + 2 * 32);   L3 = *reinterpret_cast<const v4i *>(t0 + 3 * 32);
+                }
                 if (mbi == 3 || mbx == W - 1) {
                     uint32_t qmb_v = qmb;
                     asm volatile("" : "+v"(qmb_v));
-                    const uint32_t oyuv = OYUV;
-                    const uint32_t lrow = (uint32_t)((row * 16 + j) * pitch + (mbx & ~3) * 16);   // inside the luma plane
-                    const uint32_t py = oyuv + lrow;
-                    const uint32_t pc = oyuv + plane_y + (uint32_t)(j >> 3) * plane_c + (uint32_t)((row * 8 + (j & 7)) * cpitch + (mbx & ~3) * 8);
-                    const uint32_t prgb = ORGB + lrow * 3u;
-                    const uint2 *own = reinterpret_cast<const uint2 *>(&Q.SC[j >> 3][(j & 7) * 24]);   // parked: this lane's chroma row
-                    const uint2 *pcb = reinterpret_cast<const uint2 *>(&Q.SC[0][(j >> 1) * 24]);        // parked: rows for the RGB conversion
-                    const uint2 *pcr = reinterpret_cast<const uint2 *>(&Q.SC[1][(j >> 1) * 24]);
+                    // chroma rows 2h, 2h + 1 of the lane's macroblock: parked ones from the strip, the current one from the tile
+                    const bool cur = (m_own == mbi);
+                    const uint8_t *cb_src = cur ? &Q.TC[0][(2 * h_own + 1) * 16 + 8] : &Q.SC[0][2 * h_own * 24 + m_own * 8];
+                    const uint8_t *cr_src = cur ? &Q.TC[1][(2 * h_own + 1) * 16 + 8] : &Q.SC[1][2 * h_own * 24 + m_own * 8];
+                    const int cstep = cur ? 16 : 24;
+                    const uint2 cb0 = *reinterpret_cast<const uint2 *>(cb_src), cb1 = *reinterpret_cast<const uint2 *>(cb_src + cstep);
+                    const uint2 cr0 = *reinterpret_cast<const uint2 *>(cr_src), cr1 = *reinterpret_cast<const uint2 *>(cr_src + cstep);
+                    const uint32_t x0 = (uint32_t)((mbx & ~3) * 16 + m_own * 16);
+                    const uint32_t lrow = (uint32_t)((row * 16 + 4 * h_own) * pitch) + x0;     // luma row 4h of the macroblock row
+                    const uint32_t pl = OYUV + lrow;
+                    const uint32_t pcb = OYUV + plane_y + (uint32_t)((row * 8 + 2 * h_own) * cpitch) + (x0 >> 1), pcr = pcb + plane_c;
                     if (mbi == 3) {
                         // ---- full strip: exactly VM_STRIP store instructions ----
-                        const uint2 w0 = own[0], w1 = own[1], w2 = own[2];
-                        const v4i c01 = {(int)w0.x, (int)w0.y, (int)w1.x, (int)w1.y}, c23 = {(int)w2.x, (int)w2.y, cq.x, cq.y};
+#define MVHP_ST(ADDR, DATA, BASE, OFF) asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 offset:" #OFF "\n\ts_nop 1" : : "v"(ADDR), "v"(DATA), "s"(BASE) : "memory")
+#define MVHP_ST2(ADDR, DATA, BASE) asm volatile("s_nop 4\n\tglobal_store_dwordx2 %0, %1, %2" : : "v"(ADDR), "v"(DATA), "s"(BASE) : "memory")
                         if (valid) {
-                            asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2\n\ts_nop 1" : : "v"(py), "v"(st_y0), "s"(gyuv) : "memory");
-                            asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 offset:16\n\ts_nop 1" : : "v"(py), "v"(st_y1), "s"(gyuv) : "memory");
-                            asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 offset:32\n\ts_nop 1" : : "v"(py), "v"(st_y2), "s"(gyuv) : "memory");
-                            asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 offset:48\n\ts_nop 1" : : "v"(py), "v"(yq), "s"(gyuv) : "memory");
-                            asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2\n\ts_nop 1" : : "v"(pc), "v"(c01), "s"(gyuv) : "memory");
-                            asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 offset:16\n\ts_nop 1" : : "v"(pc), "v"(c23), "s"(gyuv) : "memory");
+                            MVHP_ST(pl, L0, gyuv, 0);                MVHP_ST(pl + pitch, L1, gyuv, 0);
+                            MVHP_ST(pl + 2 * pitch, L2, gyuv, 0);    MVHP_ST(pl + 3 * pitch, L3, gyuv, 0);
+                            const v2i b0 = {(int)cb0.x, (int)cb0.y}, b1 = {(int)cb1.x, (int)cb1.y};
+                            const v2i q0 = {(int)cr0.x, (int)cr0.y}, q1 = {(int)cr1.x, (int)cr1.y};
+                            MVHP_ST2(pcb, b0, gyuv);            MVHP_ST2(pcr, q0, gyuv);
+                            MVHP_ST2(pcb + cpitch, b1, gyuv);   MVHP_ST2(pcr + cpitch, q1, gyuv);
                         }
                         if (RGB) {
-#define MVHP_RGB_OUT(YQ, CB, CR, OFF)                                                                                  \
+                            const uint32_t prgb = ORGB + lrow * 3u;
+                            // one luma row of the lane's macroblock against its chroma row (rows 2c, 2c + 1 share row c,
+                            // export_utils.c:278-279); the colour terms are recomputed per row here -- the row-pair form
+                            // of recon_oct.hip needs more registers than this kernel's 100 leave
+#define MVHP_RGB_OUT(YQ, CB, CR, R)                                                                                    \
                             {                                                                                          \
                                 v4i a0, a1, a2;                                                                        \
-                                const uint4 yy = make_uint4((uint32_t)(YQ).x, (uint32_t)(YQ).y, (uint32_t)(YQ).z, (uint32_t)(YQ).w); \
-                                MVHP_RGB16(yy, CB, CR, a0, a1, a2);                                                    \
-                                if (MVHP_RGB_STORE_COND) {                                                             \
-                                    asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 offset:" #OFF MVHP_RGB_HINT "\n\ts_nop 1" : : "v"(prgb), "v"(a0), "s"(grgb) : "memory"); \
-                                    asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 offset:" #OFF "+16" MVHP_RGB_HINT "\n\ts_nop 1" : : "v"(prgb), "v"(a1), "s"(grgb) : "memory"); \
-                                    asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 offset:" #OFF "+32" MVHP_RGB_HINT "\n\ts_nop 1" : : "v"(prgb), "v"(a2), "s"(grgb) : "memory"); \
+                                rgb16(make_uint4((uint32_t)(YQ).x, (uint32_t)(YQ).y, (uint32_t)(YQ).z, (uint32_t)(YQ).w), CB, CR, a0, a1, a2); \
+                                const uint32_t pa = prgb + (R) * 3u * (uint32_t)pitch;                                  \
+                                if (valid) {                                                                           \
+                                    MVHP_ST(pa, a0, grgb, 0); MVHP_ST(pa, a1, grgb, 16); MVHP_ST(pa, a2, grgb, 32);     \
                                 } else {                                                                               \
                                     asm volatile("" : : "v"(a0), "v"(a1), "v"(a2));                                    \
                                 }                                                                                      \
                             }
-#if defined(MVHP_ABL_NO_RGB_MATH)
-#define MVHP_RGB16(yy, CB, CR, a0, a1, a2) { a0 = v4i{(int)yy.x, (int)yy.y, (int)yy.z, (int)yy.w}; a1 = a0; a2 = a0; }
-#else
-#define MVHP_RGB16(yy, CB, CR, a0, a1, a2) rgb16(yy, CB, CR, a0, a1, a2)
-#endif
-#if defined(MVHP_ABL_NO_RGB_STORE)
-#define MVHP_RGB_STORE_COND false
-#else
-#define MVHP_RGB_STORE_COND valid
-#endif
-                            MVHP_RGB_OUT(st_y0, pcb[0], pcr[0], 0)
-                            MVHP_RGB_OUT(st_y1, pcb[1], pcr[1], 48)
-                            MVHP_RGB_OUT(st_y2, pcb[2], pcr[2], 96)
-                            MVHP_RGB_OUT(yq, cbv, crv, 144)
+                            MVHP_RGB_OUT(L0, cb0, cr0, 0u)
+                            MVHP_RGB_OUT(L1, cb0, cr0, 1u)
+                            MVHP_RGB_OUT(L2, cb1, cr1, 2u)
+                            MVHP_RGB_OUT(L3, cb1, cr1, 3u)
 #undef MVHP_RGB_OUT
-#undef MVHP_RGB16
-#undef MVHP_RGB_STORE_COND
                         }
+#undef MVHP_ST
+#undef MVHP_ST2
                         n_st = VM_STRIP;
-                    } else {
+                    } else if (m_own <= mbi && valid) {
                         // ---- short strip at the right picture edge (W % 4 != 0): compiler-counted stores ----
+                        const v4i Lr[4] = {L0, L1, L2, L3};
+                        const uint2 cbr[2] = {cb0, cb1}, crr[2] = {cr0, cr1};
 #pragma unroll
-                        for (int k = 0; k < 3; k++) {
-                            if (k > mbi) continue;
-                            const bool last = (k == mbi);
-                            const v4i yk = last ? yq : (k == 0 ? st_y0 : st_y1);
-                            const uint2 ow = own[k], pb = pcb[k], pr = pcr[k];   // read first, then choose values (not addresses)
-                            uint2 ck, cbk, crk;
-                            ck.x = last ? cv.x : ow.x; ck.y = last ? cv.y : ow.y;
-                            cbk.x = last ? cbv.x : pb.x; cbk.y = last ? cbv.y : pb.y;
-                            crk.x = last ? crv.x : pr.x; crk.y = last ? crv.y : pr.y;
-                            if (valid) {
-                                *reinterpret_cast<v4i *>(gyuv + py + k * 16) = yk;
-                                *reinterpret_cast<uint2 *>(gyuv + pc + k * 8) = ck;
-                            }
+                        for (int i = 0; i < 2; i++) {
+                            *reinterpret_cast<v4i *>(gyuv + pl + 2 * i * pitch) = Lr[2 * i];
+                            *reinterpret_cast<v4i *>(gyuv + pl + (2 * i + 1) * pitch) = Lr[2 * i + 1];
+                            *reinterpret_cast<uint2 *>(gyuv + pcb + i * cpitch) = cbr[i];
+                            *reinterpret_cast<uint2 *>(gyuv + pcr + i * cpitch) = crr[i];
                             if (RGB) {
-                                v4i a0, a1, a2;
-                                const uint4 yy = make_uint4((uint32_t)yk.x, (uint32_t)yk.y, (uint32_t)yk.z, (uint32_t)yk.w);
-                                rgb16(yy, cbk, crk, a0, a1, a2);
-                                if (valid) {
-                                    v4i *dst = reinterpret_cast<v4i *>(grgb + prgb + k * 48);
+                                const uint32_t prgb = ORGB + lrow * 3u;
+#pragma unroll
+                                for (int r = 0; r < 2; r++) {
+                                    v4i a0, a1, a2;
+                                    const v4i yk = Lr[2 * i + r];
+                                    rgb16(make_uint4((uint32_t)yk.x, (uint32_t)yk.y, (uint32_t)yk.z, (uint32_t)yk.w), cbr[i], crr[i], a0, a1, a2);
+                                    v4i *dst = reinterpret_cast<v4i *>(grgb + prgb + (2 * i + r) * 3u * (uint32_t)pitch);
                                     dst[0] = a0; dst[1] = a1; dst[2] = a2;
                                 }
                             }
                         }
                     }
                 } else {
-                    // ---- park: luma row in a register, chroma row in the LDS strip ----
+                    // ---- park the chroma rows (lane j: row j & 7 of plane j >> 3) in the LDS strip ----
+                    const uint2 cv = *reinterpret_cast<const uint2 *>(&Q.TC[j >> 3][((j & 7) + 1) * 16 + 8]);
                     *reinterpret_cast<uint2 *>(&Q.SC[j >> 3][(j & 7) * 24 + mbi * 8]) = cv;
-                    if (mbi == 0) st_y0 = yq;
-                    else if (mbi == 1) st_y1 = yq;
-                    else st_y2 = yq;
                 }
             }
 

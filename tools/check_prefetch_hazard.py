@@ -36,7 +36,7 @@ def regs(tok):
 
 # kernel family -> (prefetch registers, asm loads per prefetch block, stores of a full strip without / with RGB)
 FAMILIES = {
-    "recon_quad_kernel": (set(range(100, 124)), 6, (6, 18)),
+    "recon_quad_kernel": (set(range(100, 124)), 6, (8, 20)),
     "recon_oct_kernel": (set(range(216, 248)), 8, (16, 40)),
 }
 
