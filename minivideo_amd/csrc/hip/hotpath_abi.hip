@@ -3,6 +3,7 @@
 // reconstruction entry point fails with MVHP_FAILURE and a message.
 #include <hip/hip_runtime.h>
 #include <stdarg.h>
+#include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -181,15 +182,22 @@ static int pick_layout(const mvhp_ctx *c, const mvhp_stream_params_t *p, int n_f
 {
     int layout = c->layout;
     if (layout == MVHP_LAYOUT_AUTO) {
-        // speed only: four pictures per workgroup wants ~4 * CUs pictures before every CU has work; measured crossover
-        // against the one-picture kernel on 1080p: between 512 and 768 pictures
-        layout = (n_frames >= 3 * c->n_cus) ? MVHP_LAYOUT_QUAD : MVHP_LAYOUT_ROWS;
-        // eight pictures per workgroup (one 8-wave workgroup per CU) from 8 * CUs pictures: fewer instructions per
-        // macroblock and full-line writes; measured 1.16x the four-picture kernel on Baseline content with RGB output and
-        // 1.03x on High content (Intra8x8: 12.8 vs 13.2 ms per 2048 x 1080p).  Only while its eight waves fit into LDS
-        // (pictures up to 156 macroblocks wide): with six waves it loses to the four-picture kernel (2160p High, 2048
-        // pictures: 0.99 vs 1.29 x 10^9 MB/s).
-        if (n_frames >= 8 * c->n_cus && mvhp::recon_oct_lds_bytes((int)p->width_mbs, 8) <= c->max_lds) layout = MVHP_LAYOUT_OCT;
+        // speed only.  A launch is a number of "rounds" of one workgroup per CU (the batch kernels fill a CU with one
+        // workgroup); measured on 1080p, in units of one full round of the four-picture kernel (5.4 ms for 4 * CUs
+        // pictures): a round of the one-picture kernel (CUs pictures) 0.47; the four-picture kernel 0.77 with one
+        // workgroup on the device .. 1.0 with all CUs busy; the eight-picture kernel 1.48 .. 1.85 (8 * CUs pictures).
+        // (tools/layout_crossover.py: Baseline 256 pictures rows 2.6 / quad 4.2 / oct 8.0 ms, 1024: 8.7 / 5.4 / 8.3,
+        // 1536: 12.2 / 9.7 / 8.6, 2048: 15.8 / 10.6 / 10.0; High the same order.)
+        const double cus = (double)c->n_cus;
+        auto rounds = [&](double per_round, double lo, double hi) {
+            const double full = floor(n_frames / per_round), rem = n_frames - full * per_round;
+            return full * hi + (rem > 0 ? lo + (hi - lo) * rem / per_round : 0.0);
+        };
+        const double t_rows = ceil(n_frames / cus) * 0.47;
+        const double t_quad = rounds(4 * cus, 0.77, 1.0);
+        const bool oct_fits = mvhp::recon_oct_lds_bytes((int)p->width_mbs, 8) <= c->max_lds;   // with six waves it loses to quad
+        const double t_oct = oct_fits ? rounds(8 * cus, 1.48, 1.85) : 1e30;
+        layout = (t_rows <= t_quad && t_rows <= t_oct) ? MVHP_LAYOUT_ROWS : (t_oct < t_quad ? MVHP_LAYOUT_OCT : MVHP_LAYOUT_QUAD);
     }
     // the batch kernels address a workgroup's pictures with 32-bit offsets and keep one line buffer per picture in LDS
     const size_t mbs = (size_t)p->width_mbs * p->height_mbs;

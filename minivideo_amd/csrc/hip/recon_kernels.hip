@@ -714,11 +714,10 @@ __global__ __launch_bounds__(NW * 64) void recon_rows_kernel(ReconArgs a)
                             const uint32_t crw = *reinterpret_cast<const uint16_t *>(&Wv.SC[1][(y >> 1) * 32 + (x4 >> 1)]);
                             int d0, d1, d2;   // packed 16-bit arithmetic, see recon_batch_device.h rgb4()
                             rgb4(yw, bytes01(cbw), bytes01(crw), d0, d1, d2);
-                            uint32_t *dst = reinterpret_cast<uint32_t *>(
-                                frgb + ((size_t)(row * 16 + y) * pitch + x0 * 16 + x4) * 3);
-                            dst[0] = (uint32_t)d0;
-                            dst[1] = (uint32_t)d1;
-                            dst[2] = (uint32_t)d2;
+                            // one 12-byte store per lane: the 16 lanes of a row cover its 192 bytes in one instruction
+                            typedef int v3i __attribute__((ext_vector_type(3)));
+                            typedef v3i v3i_a4 __attribute__((aligned(4)));
+                            *reinterpret_cast<v3i_a4 *>(frgb + ((size_t)(row * 16 + y) * pitch + x0 * 16 + x4) * 3) = v3i{d0, d1, d2};
                         }
                     }
                 }
@@ -774,10 +773,12 @@ __global__ __launch_bounds__(256) void ycbcr_to_rgb_kernel(ColorArgs a)
             o[q * 3 + 1] = (uint8_t)clip255(ly - ((100 * cb) >> 8) - ((208 * cr) >> 8) + 135);
             o[q * 3 + 2] = (uint8_t)clip255(ly + ((516 * cb) >> 8) - 276);
         }
-        uint32_t *dst = reinterpret_cast<uint32_t *>(a.rgb + (size_t)frame * Wp * Hp * 3 + ((size_t)y * Wp + xq * 4) * 3);
-        dst[0] = o[0] | (o[1] << 8) | (o[2] << 16) | ((uint32_t)o[3] << 24);
-        dst[1] = o[4] | (o[5] << 8) | (o[6] << 16) | ((uint32_t)o[7] << 24);
-        dst[2] = o[8] | (o[9] << 8) | (o[10] << 16) | ((uint32_t)o[11] << 24);
+        typedef int v3i __attribute__((ext_vector_type(3)));
+        typedef v3i v3i_a4 __attribute__((aligned(4)));
+        *reinterpret_cast<v3i_a4 *>(a.rgb + (size_t)frame * Wp * Hp * 3 + ((size_t)y * Wp + xq * 4) * 3) =   // one 12-byte store
+            v3i{(int)(o[0] | (o[1] << 8) | (o[2] << 16) | ((uint32_t)o[3] << 24)),
+                (int)(o[4] | (o[5] << 8) | (o[6] << 16) | ((uint32_t)o[7] << 24)),
+                (int)(o[8] | (o[9] << 8) | (o[10] << 16) | ((uint32_t)o[11] << 24))};
     }
 }
 

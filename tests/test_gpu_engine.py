@@ -99,7 +99,7 @@ def test_engine_wanted_caps_entropy_work():
 
 @pytest.mark.parametrize("batch,layout", [(1024, 2), (2048, 3)])
 def test_engine_reaches_the_batch_kernels(batch, layout):
-    """>= 3 x CUs pictures in one launch -> four pictures per workgroup; >= 8 x CUs (no 8x8 transform) -> eight."""
+    """4 x CUs pictures in one launch -> four pictures per workgroup; 8 x CUs -> eight (pick_layout, hotpath_abi.hip)."""
     W, H, D = 12, 6, 32
     F = 2080
     stream, packed = gen.make_stream(W, H, D, seed=80, profile="baseline")
