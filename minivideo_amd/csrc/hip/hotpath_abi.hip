@@ -509,9 +509,16 @@ int eng_h2d(DevCtx *d, int n, void *const *dst, const void *const *src, const si
     return MVHP_SUCCESS;
 }
 
-int eng_d2h(DevCtx *d, void *dst, const void *src, size_t bytes, float *ms, std::string &err)
+int eng_d2h(DevCtx *d, int n, void *const *dst, const void *const *src, const size_t *bytes, float *ms, std::string &err)
 {
-    return eng_copy(d, d->down, d->ev[4], d->ev[5], dst, src, bytes, hipMemcpyDeviceToHost, ms, err);
+    ENG_TRY(hipSetDevice(d->c->device));
+    ENG_TRY(hipEventRecord(d->ev[4], d->down));
+    for (int i = 0; i < n; i++)
+        if (bytes[i]) ENG_TRY(hipMemcpyAsync(dst[i], src[i], bytes[i], hipMemcpyDeviceToHost, d->down));
+    ENG_TRY(hipEventRecord(d->ev[5], d->down));
+    ENG_TRY(hipEventSynchronize(d->ev[5]));
+    if (ms) ENG_TRY(hipEventElapsedTime(ms, d->ev[4], d->ev[5]));
+    return MVHP_SUCCESS;
 }
 
 int eng_recon(DevCtx *d, const mvhp_stream_params_t *p, const void *d_compact, size_t stride, void *d_packed, int n, uint8_t *d_yuv,

@@ -142,6 +142,7 @@ struct Batch {
     std::string dead_why;
     DevBuf *buf = nullptr;
     std::deque<InChunk *> ready;     // entropy-decoded chunks waiting for upload
+    double t_open = 0, t_claim = 0, t_closed = 0, t_uploaded = 0, t_kernel = 0;   // MINIVIDEO_ENGINE_TRACE (seconds into the call)
 };
 
 struct Item {
@@ -159,7 +160,9 @@ struct RetryGroup {
 struct Ctx {
     DevCtx *dev = nullptr;
     int device = 0;
-    DevBuf bufs[2];
+    DevBuf bufs[3];   // three batches per context: one filling / uploading, one in the kernel, one downloading -- with two, the batch
+                      // after next could not be claimed until a download finished and the entropy threads ran out of chunk slots
+                      // (170 pictures took 90 ms instead of 44 to fill in the taper of a 2048-picture job)
     int open_batch = -1;
     std::deque<int> to_launch, to_download;
     bool fail_next = false;
@@ -222,7 +225,8 @@ private:
     std::deque<InChunk *> free_in_;
     std::deque<OutChunk *> free_out_;
     mvhp_decode_stats_t st_{};
-    std::vector<double> worker_busy_;
+    std::vector<double> worker_busy_, worker_wait_;   // per entropy thread: inside decode_compact / waiting for work
+    double feeder_wait_chunk_ = 0, t_last_entropy_ = 0, t_last_download_ = 0, t_start_ = 0;   // MINIVIDEO_ENGINE_TRACE
     std::atomic<uint64_t> stream_bytes_{0};
 };
 
@@ -274,7 +278,7 @@ bool Engine::init(const mvhp_engine_opts_t *opts, std::string &err)
         int sharers = 0;
         for (int j = 0; j < n_ctx; j++) sharers += ctx_[j].device == ctx_[k].device;
         const size_t free_b = api_.dev_free_bytes(ctx_[k].dev);
-        ctx_[k].mem_budget = free_b / 2 / 2 / (size_t)std::max(1, sharers);
+        ctx_[k].mem_budget = free_b / 2 / 3 / (size_t)std::max(1, sharers);   // half of what is free, three batches
     }
     return true;
 }
@@ -350,6 +354,7 @@ bool Engine::ensure_devbuf(Ctx &c, DevBuf &b, const Batch &bt, std::string &err)
 void Engine::close_batch(Batch *b)
 {
     b->total = (int)b->seqs.size();
+    b->t_closed = now_s() - t_start_;
     st_.max_batch_pictures = std::max(st_.max_batch_pictures, (uint32_t)b->total);
     if (b->ctx >= 0 && b->uploaded == b->total) {
         Ctx &cx = ctx_[(size_t)b->ctx];
@@ -402,6 +407,7 @@ void Engine::feeder()
             nb->retry = rg != nullptr;
             nb->exclude_ctx = rg ? rg->exclude_ctx : -1;
             nb->seqs.reserve((size_t)nb->capacity);
+            nb->t_open = now_s() - t_start_;
             cur = nb.get();
             batches_[cur->id] = std::move(nb);
         }
@@ -426,7 +432,9 @@ void Engine::feeder()
                 c = all_in_.back().get();
                 break;
             }
+            const double w0 = now_s();
             cv_.wait(l);
+            feeder_wait_chunk_ += now_s() - w0;
         }
         if (!c) continue;   // stopping: the head of the loop closes the batch
         bool have_mem = true;
@@ -492,8 +500,10 @@ void Engine::worker(int t)
         Item it;
         {
             std::unique_lock<std::mutex> l(mu_);
+            const double w0 = now_s();
             cv_.wait(l, [&] { return stop_ || !work_q_.empty(); });
             if (stop_) return;
+            worker_wait_[(size_t)t] += now_s() - w0;
             it = work_q_.front();
             work_q_.pop_front();
         }
@@ -509,10 +519,12 @@ void Engine::worker(int t)
         }
         it.chunk->used[(size_t)it.slot] = used;   // (each slot has one writer; read by the uploader behind the engine mutex)
         worker_busy_[(size_t)t] += now_s() - t0;
+        bool wake = false;
         if (idr >= 0 && (size_t)idr < s_->idrs.size()) stream_bytes_ += s_->samples[s_->idrs[(size_t)idr].sample].nal_size;
         {
             std::lock_guard<std::mutex> l(mu_);
             PicResult &r = results_[(size_t)it.seq];
+            t_last_entropy_ = now_s() - t_start_;
             if (rc == h264::RC_SUCCESS) {
                 r.parsed_ok = true;
             } else {   // final: entropy decoding is deterministic, a second try would fail the same way
@@ -521,13 +533,17 @@ void Engine::worker(int t)
                 r.err = err;
                 r.ready = true;
             }
+            wake = rc != h264::RC_SUCCESS;   // a final result: the sink may be waiting for exactly this picture
             if (--it.chunk->remaining == 0) {
                 auto bi = batches_.find(it.chunk->batch);
                 if (bi != batches_.end()) bi->second->ready.push_back(it.chunk);
                 else free_in_.push_back(it.chunk);
+                wake = true;                 // a chunk for the uploader (or back in the pool for the feeder)
             }
         }
-        cv_.notify_all();
+        // (every waiter shares one condition variable: waking them per picture cost the sixteen entropy threads' CPU quota --
+        //  a decoded picture inside an unfinished chunk changes nothing anyone waits for)
+        if (wake) cv_.notify_all();
     }
 }
 
@@ -545,13 +561,16 @@ bool Engine::pick_chunk(int k, InChunk **c, Batch **b)
         *b = ob;
         return true;
     }
-    DevBuf *fb = !cx.bufs[0].busy ? &cx.bufs[0] : (!cx.bufs[1].busy ? &cx.bufs[1] : nullptr);
+    DevBuf *fb = nullptr;
+    for (DevBuf &d : cx.bufs)
+        if (!d.busy) { fb = &d; break; }
     if (!fb) return false;
     for (auto &kv : batches_) {   // lowest id first: batches are claimed in the order they were opened
         Batch *nb = kv.second.get();
         if (nb->ctx >= 0 || nb->ready.empty()) continue;
         if (nb->exclude_ctx == k) continue;
         nb->ctx = k;
+        nb->t_claim = now_s() - t_start_;
         nb->buf = fb;
         fb->busy = true;
         cx.open_batch = nb->id;
@@ -635,6 +654,7 @@ void Engine::uploader(int k)
             free_in_.push_back(c);
             if (b->total >= 0 && b->uploaded == b->total) {
                 cx.open_batch = -1;
+                b->t_uploaded = now_s() - t_start_;
                 if (b->dead) fail_batch(b, b->dead_why);
                 else cx.to_launch.push_back(b->id);
             }
@@ -670,6 +690,7 @@ void Engine::launcher(int k)
                 st_.batches++;
                 st_.kernel_s += ms * 1e-3;
                 if (layout >= 0 && layout < 4) st_.launches_by_layout[layout]++;
+                b->t_kernel = now_s() - t_start_;
                 cx.to_download.push_back(b->id);
             } else {
                 fail_batch(b, err);
@@ -722,8 +743,15 @@ void Engine::downloader(int k)
             float ms = 0.f, ms2 = 0.f;
             bool ok = (!want_yuv_ || grow(oc->yuv, (size_t)C * yb)) && (!want_rgb_ || grow(oc->rgb, (size_t)C * rb));
             if (!ok) err = "out of page-locked host memory";
-            if (ok && want_yuv_) ok = api_.d2h(cx.dev, oc->yuv.p, b->buf->yuv + (size_t)g * yb, (size_t)n * yb, &ms, err) == MVHP_SUCCESS;
-            if (ok && want_rgb_) ok = api_.d2h(cx.dev, oc->rgb.p, b->buf->rgb + (size_t)g * rb, (size_t)n * rb, &ms2, err) == MVHP_SUCCESS;
+            if (ok) {
+                void *dst[2];
+                const void *src[2];
+                size_t nb[2];
+                int np = 0;
+                if (want_yuv_) { dst[np] = oc->yuv.p; src[np] = b->buf->yuv + (size_t)g * yb; nb[np++] = (size_t)n * yb; }
+                if (want_rgb_) { dst[np] = oc->rgb.p; src[np] = b->buf->rgb + (size_t)g * rb; nb[np++] = (size_t)n * rb; }
+                ok = api_.d2h(cx.dev, np, dst, src, nb, &ms, err) == MVHP_SUCCESS;
+            }
             {
                 std::lock_guard<std::mutex> l(mu_);
                 if (ok) {
@@ -750,6 +778,10 @@ void Engine::downloader(int k)
         }
         {
             std::lock_guard<std::mutex> l(mu_);
+            t_last_download_ = now_s() - t_start_;
+            if (getenv("MINIVIDEO_ENGINE_TRACE"))
+                fprintf(stderr, "engine trace: batch %d: %d pictures, opened %.4f claimed %.4f closed %.4f uploaded %.4f kernel done %.4f downloaded %.4f\n",
+                        b->id, b->total, b->t_open, b->t_claim, b->t_closed, b->t_uploaded, b->t_kernel, t_last_download_);
             if (!fail.empty()) fail_batch(b, fail);   // pictures already delivered stay delivered
             else release_batch(b);
         }
@@ -782,12 +814,16 @@ int Engine::decode(const mvhp_stream &s, const int *order, int n_order, int want
         free_in_.clear(); free_out_.clear();
         for (auto &c : all_in_) free_in_.push_back(c.get());
         for (auto &c : all_out_) { c->refs = 0; free_out_.push_back(c.get()); }
-        for (Ctx &c : ctx_) { c.open_batch = -1; c.to_launch.clear(); c.to_download.clear(); c.bufs[0].busy = c.bufs[1].busy = false; c.fail_next = false; }
+        for (Ctx &c : ctx_) { c.open_batch = -1; c.to_launch.clear(); c.to_download.clear(); for (DevBuf &d : c.bufs) d.busy = false; c.fail_next = false; }
         if (opts_.fail_context >= 0 && opts_.fail_context < n_ctx) ctx_[(size_t)opts_.fail_context].fail_next = true;
         memset(&st_, 0, sizeof(st_));
         worker_busy_.assign((size_t)host_threads_, 0.0);
+        worker_wait_.assign((size_t)host_threads_, 0.0);
+        feeder_wait_chunk_ = t_last_entropy_ = t_last_download_ = 0;
+        t_start_ = t_start;
         stream_bytes_ = 0;
-        // pools: enough input chunks that every entropy thread has a slot to write while the earlier chunks upload, and
+        // pools: enough input chunks that every entropy thread has a slot to write while the earlier chunks upload (three
+        // pictures per thread were measured too: no gain, and page-locking the extra chunks costs the first call 0.1 s), and
         // a few output chunks per context
         mvhp_stream_params_t p0{};
         int C = 8;
@@ -814,10 +850,12 @@ int Engine::decode(const mvhp_stream &s, const int *order, int n_order, int want
         {
             std::unique_lock<std::mutex> l(mu_);
             if (ok_ >= wanted_) break;
-            sink_waiting_ = true;
-            cv_.notify_all();
-            cv_.wait(l, [&] { return results_[(size_t)next].ready; });
-            sink_waiting_ = false;
+            if (!results_[(size_t)next].ready) {
+                sink_waiting_ = true;   // (lets the downloader grow its pool rather than deadlock behind a re-queued batch)
+                cv_.notify_all();
+                cv_.wait(l, [&] { return results_[(size_t)next].ready; });
+                sink_waiting_ = false;
+            }
             r = results_[(size_t)next];
         }
         int verdict = (r.rc == MVHP_SUCCESS) ? 1 : 0;
@@ -826,15 +864,16 @@ int Engine::decode(const mvhp_stream &s, const int *order, int n_order, int want
             verdict = sink(user, next, r.idr, r.rc, r.err.c_str(), &r.params, r.yuv, r.rgb);
             sink_s += now_s() - t0;
         }
+        bool wake = false;
         {
             std::lock_guard<std::mutex> l(mu_);
-            if (r.oc && --r.oc->refs == 0) put_out(r.oc);
+            if (r.oc && --r.oc->refs == 0) { put_out(r.oc); wake = true; }   // an output chunk for the downloader
             results_[(size_t)next].oc = nullptr;
             consumed_++;
             if (r.rc == MVHP_SUCCESS && verdict == 1) ok_++;
-            else failed_++;
+            else { failed_++; wake = true; }                                  // the allowance grew: the feeder may issue another picture
         }
-        cv_.notify_all();
+        if (wake) cv_.notify_all();
         next++;
         if (verdict < 0) { aborted = true; break; }
     }
@@ -856,6 +895,14 @@ int Engine::decode(const mvhp_stream &s, const int *order, int n_order, int want
         st_.stream_bytes = stream_bytes_;
         for (double b : worker_busy_) st_.entropy_busy_s += b;
         st_.wall_s = now_s() - t_start;
+        if (getenv("MINIVIDEO_ENGINE_TRACE")) {   // where the wall time went (developer aid)
+            double wait = 0, wmax = 0, bmin = 1e30, bmax = 0;
+            for (double w : worker_wait_) { wait += w; wmax = std::max(wmax, w); }
+            for (double b : worker_busy_) { bmin = std::min(bmin, b); bmax = std::max(bmax, b); }
+            fprintf(stderr, "engine trace: wall %.4f s, threads %d: busy min %.4f max %.4f, waiting for work sum %.4f max %.4f; feeder waited %.4f s for a free "
+                            "input chunk; last entropy result at %.4f s, last download at %.4f s, sink %.4f s, batches %u\n",
+                    st_.wall_s, threads, bmin, bmax, wait, wmax, feeder_wait_chunk_, t_last_entropy_, t_last_download_, sink_s, st_.batches);
+        }
         if (stats) *stats = st_;
         s_ = nullptr; order_ = nullptr;
     }

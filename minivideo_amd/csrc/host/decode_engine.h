@@ -34,7 +34,8 @@ struct DeviceApi {
     size_t (*dev_free_bytes)(DevCtx *c);
     // n pieces in one go (one piece per picture: compact pictures have individual sizes)
     int    (*h2d)(DevCtx *c, int n, void *const *d_dst, const void *const *h_src, const size_t *bytes, float *ms, std::string &err);
-    int    (*d2h)(DevCtx *c, void *h_dst, const void *d_src, size_t bytes, float *ms, std::string &err);
+    // n pieces in one go (the planes and the RGB of an output chunk: one wait instead of two)
+    int    (*d2h)(DevCtx *c, int n, void *const *h_dst, const void *const *d_src, const size_t *bytes, float *ms, std::string &err);
     // compact pictures (`stride` bytes apart) -> packed records in d_packed (scratch) -> planes (+ RGB)
     int    (*recon)(DevCtx *c, const mvhp_stream_params_t *p, const void *d_compact, size_t stride, void *d_packed,
                     int n_pictures, uint8_t *d_yuv, uint8_t *d_rgb, float *ms, int *layout, int *waves, std::string &err);

@@ -54,14 +54,7 @@ void stub_ctx_destroy(DevCtx *c) { g_live_ctx--; delete c; }
 void *stub_dev_alloc(DevCtx *, size_t n) { g_dev_allocs++; return malloc(n ? n : 1); }
 void stub_dev_free(DevCtx *, void *p) { g_dev_allocs--; free(p); }
 size_t stub_dev_free_bytes(DevCtx *) { return (size_t)1 << 32; }
-int stub_copy(DevCtx *, void *dst, const void *src, size_t n, float *ms, std::string &)
-{
-    memcpy(dst, src, n);
-    std::this_thread::sleep_for(std::chrono::microseconds(50));
-    if (ms) *ms = 0.05f;
-    return MVHP_SUCCESS;
-}
-int stub_h2d(DevCtx *, int n, void *const *dst, const void *const *src, const size_t *bytes, float *ms, std::string &)
+int stub_copy_n(DevCtx *, int n, void *const *dst, const void *const *src, const size_t *bytes, float *ms, std::string &)
 {
     for (int i = 0; i < n; i++) memcpy(dst[i], src[i], bytes[i]);
     std::this_thread::sleep_for(std::chrono::microseconds(50));
@@ -115,7 +108,7 @@ int stub_recon(DevCtx *, const mvhp_stream_params_t *p, const void *d_compact, s
 }
 
 const mvengine::DeviceApi g_stub = {stub_device_count, stub_host_alloc, stub_host_free, stub_ctx_create, stub_ctx_destroy,
-                                    stub_dev_alloc, stub_dev_free, stub_dev_free_bytes, stub_h2d, stub_copy, stub_recon};
+                                    stub_dev_alloc, stub_dev_free, stub_dev_free_bytes, stub_copy_n, stub_copy_n, stub_recon};
 
 struct Check {
     const mvhp_stream *s = nullptr;
