@@ -147,7 +147,7 @@ __device__ __forceinline__ void rgb16(const uint4 yv, const uint2 cbv, const uin
 }
 
 // The same split in two: the chroma terms of a pair of chroma samples (four luma samples wide), and their use on one
-// luma word.  Two luma rows share a chroma row (export_utils.c:278-279), so a lane that owns rows 2j and 2j+1 computes
+// luma word.  Two luma rows share a chroma row (export_utils.c:278-279), so a lane that owns both rows of a pair computes
 // the terms once.
 struct RgbTerms {
     s16x2 rtl, rth, gtl, gth, btl, bth;

@@ -13,8 +13,9 @@
 //   * everything that is paid once per step (header decoding, the row-above wait, neighbour bookkeeping) is shared
 //     by eight macroblocks.
 // Lane j of an octet owns luma 4x4 blocks 2j and 2j+1 (64 contiguous bytes of the record: for an Intra8x8 macroblock
-// the same bytes are rows 4(j&1)..+3 of 8x8 block j>>1), chroma block j, luma rows 2j and 2j+1 and chroma row j of
-// both planes of the finished macroblock.
+// the same bytes are rows 4(j&1)..+3 of 8x8 block j>>1) and chroma block j.  The finished macroblock is written out by
+// OWNER lanes: lane (m, h) = (j & 3, j >> 2) keeps eight luma rows of macroblock m of the 4-macroblock output strip (see
+// the write-out).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -760,9 +761,7 @@ MVHP_MARK("p_i8");
             WAVE_SYNC();
 
             // =====================================================================================
-            // write-out (mb_to_rgb, export_utils.c:209-324, fused): lane j holds luma rows 2j, 2j+1 and chroma row j of both
-            // planes -- the chroma row those two luma rows share (export_utils.c:278-279), so its colour terms are
-            // computed once; park, or flush the 4-macroblock strip
+            // write-out (mb_to_rgb, export_utils.c:209-324, fused): park, or flush the 4-macroblock strip
             // =====================================================================================
             // Strip ownership by MACROBLOCK: lane (m, h) = (j & 3, j >> 2) of an octet keeps, of macroblock m of the 4-macroblock
             // strip, luma rows 4i + 2h, 4i + 2h + 1 (i < 4) -- pairs that share chroma row 2i + h -- and writes them when the

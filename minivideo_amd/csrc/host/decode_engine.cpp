@@ -300,8 +300,8 @@ int Engine::chunk_pictures(const mvhp_stream_params_t &p) const
     return (int)std::min<size_t>(64, std::max<size_t>(1, ((size_t)64 << 20) / pb));
 }
 
-// pictures per launch.  Speed only.  The batch kernels want >= 3 x CUs (four pictures per workgroup) or >= 8 x CUs
-// (eight) pictures, but the host entropy stage is the slow side and the download of a batch (9.4 MB per 1080p picture) is
+// pictures per launch.  Speed only.  The batch kernels want 4 x CUs (four pictures per workgroup) or 8 x CUs (eight)
+// pictures, but the host entropy stage is the slow side and the download of a batch (9.4 MB per 1080p picture) is
 // next: what matters is that downloads start early and that the job's last download is short.  So batches RAMP UP from 64
 // pictures, doubling, to the cap (the download of batch k hides behind the entropy work of batch k+1 as long as batches
 // do not shrink faster than the link is quicker than the entropy stage), and TAPER at the end (each takes at most 35 %
