@@ -63,6 +63,18 @@ __device__ __forceinline__ uint32_t sat_pk_u8(int v)
     return o;
 }
 
+// level * LevelScale + addend with the 16-bit level taken straight out of its packed word (v_mad_i32_i16: signed 16-bit
+// operands selected by op_sel, 32-bit addend): one instruction where extracting the half and a 24-bit multiply were two.
+// `ls` must fit int16 (LevelScale << shift is at most 4096 for 4x4 and 2304 for 8x8).
+template <int HI>
+__device__ __forceinline__ int mad_level(int pk, int ls, int addend)
+{
+    int d;
+    if (HI) asm("v_mad_i32_i16 %0, %1, %2, %3 op_sel:[1,0,0,0]" : "=v"(d) : "v"(pk), "v"(ls), "v"(addend));
+    else asm("v_mad_i32_i16 %0, %1, %2, %3" : "=v"(d) : "v"(pk), "v"(ls), "v"(addend));
+    return d;
+}
+
 // Prediction (four row words of four samples) + residual (eight packed int16 pairs) -> tile.
 __device__ __forceinline__ void emit_block(uint8_t *dst, int pitch, const uint32_t pw[4], const int r2[8])
 {

@@ -286,9 +286,8 @@ MVHP_MARK("r_8x8");
                         const int k2 = (t == 0) ? q4 : (t == 2) ? q2 : q5;   // columns 2, 6
 #pragma unroll
                         for (int c = 0; c < 8; c++) {
-                            const int lv = (c & 1) ? (pkw[c >> 1] >> 16) : (int)(short)(pkw[c >> 1] & 0xffff);
                             const int ls = (c & 1) ? k1 : ((c & 3) == 0 ? k0 : k2);
-                            dr[t][c] = (__mul24(lv, ls) + rnd8) >> shr8;
+                            dr[t][c] = ((c & 1) ? mad_level<1>(pkw[c >> 1], ls, rnd8) : mad_level<0>(pkw[c >> 1], ls, rnd8)) >> shr8;
                         }
                     }
                     if (hh == 0) dr[0][0] += 32; // rounding term of the final (m + 32) >> 6, see idct4x4
@@ -359,16 +358,14 @@ MVHP_MARK("r_4x4");
                             for (int i = 0; i < 16; i++) {
                                 const int r = i >> 2, c = i & 3;
                                 const int ls = ((r & 1) == 0 && (c & 1) == 0) ? qt.x : (((r & 1) && (c & 1)) ? qt.y : qt.z);
-                                const int lv = (i & 1) ? (pk[i >> 1] >> 16) : (int)(short)(pk[i >> 1] & 0xffff);
-                                d[i] = __mul24(lv, ls);
+                                d[i] = (i & 1) ? mad_level<1>(pk[i >> 1], ls, 0) : mad_level<0>(pk[i >> 1], ls, 0);
                             }
                         } else {
 #pragma unroll
                             for (int i = 0; i < 16; i++) {
                                 const int r = i >> 2, c = i & 3;
                                 const int ls = ((r & 1) == 0 && (c & 1) == 0) ? qt.x : (((r & 1) && (c & 1)) ? qt.y : qt.z);
-                                const int lv = (i & 1) ? (pk[i >> 1] >> 16) : (int)(short)(pk[i >> 1] & 0xffff);
-                                d[i] = (__mul24(lv, ls) + rnd) >> shr;
+                                d[i] = ((i & 1) ? mad_level<1>(pk[i >> 1], ls, rnd) : mad_level<0>(pk[i >> 1], ls, rnd)) >> shr;
                             }
                         }
                         if (kind == MVHP_KIND_I16x16) d[0] = sl ? dc1 : dc0;
@@ -409,16 +406,14 @@ MVHP_MARK("r_4x4");
                     for (int i = 1; i < 16; i++) {
                         const int r = i >> 2, c = i & 3;
                         const int ls = ((r & 1) == 0 && (c & 1) == 0) ? qt.x : (((r & 1) && (c & 1)) ? qt.y : qt.z);
-                        const int lv = (i & 1) ? (pk[i >> 1] >> 16) : (int)(short)(pk[i >> 1] & 0xffff);
-                        d[i] = __mul24(lv, ls);
+                        d[i] = (i & 1) ? mad_level<1>(pk[i >> 1], ls, 0) : mad_level<0>(pk[i >> 1], ls, 0);
                     }
                 } else {
 #pragma unroll
                     for (int i = 1; i < 16; i++) {
                         const int r = i >> 2, c = i & 3;
                         const int ls = ((r & 1) == 0 && (c & 1) == 0) ? qt.x : (((r & 1) && (c & 1)) ? qt.y : qt.z);
-                        const int lv = (i & 1) ? (pk[i >> 1] >> 16) : (int)(short)(pk[i >> 1] & 0xffff);
-                        d[i] = (__mul24(lv, ls) + rnd) >> shr;
+                        d[i] = ((i & 1) ? mad_level<1>(pk[i >> 1], ls, rnd) : mad_level<0>(pk[i >> 1], ls, rnd)) >> shr;
                     }
                 }
                 d[0] = dc + 32;

@@ -284,22 +284,20 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_num_vgpr(100))) void
                     }
                     // quant4x4, h264_transform.c:1100-1134: ((c*LS + rnd) >> shr) << shl, the left shift folded into LS;
                     // shr = rnd = 0 from qP 24 up (checked for the whole wave).  The levels are multiplied straight out
-                    // of the packed words (the 16-bit selection is an operand modifier of v_mul_i32_i24).
+                    // of the packed words (mad_level: v_mad_i32_i16 selects the 16-bit half itself).
                     if (__builtin_amdgcn_ballot_w64(shr != 0) == 0) {
 #pragma unroll
                         for (int i = 0; i < 16; i++) {
                             const int r = i >> 2, c = i & 3;
                             const int ls = ((r & 1) == 0 && (c & 1) == 0) ? qt.x : (((r & 1) && (c & 1)) ? qt.y : qt.z);
-                            const int lv = (i & 1) ? (pk[i >> 1] >> 16) : (int)(short)(pk[i >> 1] & 0xffff);
-                            d[i] = __mul24(lv, ls);
+                            d[i] = (i & 1) ? mad_level<1>(pk[i >> 1], ls, 0) : mad_level<0>(pk[i >> 1], ls, 0);
                         }
                     } else {
 #pragma unroll
                         for (int i = 0; i < 16; i++) {
                             const int r = i >> 2, c = i & 3;
                             const int ls = ((r & 1) == 0 && (c & 1) == 0) ? qt.x : (((r & 1) && (c & 1)) ? qt.y : qt.z);
-                            const int lv = (i & 1) ? (pk[i >> 1] >> 16) : (int)(short)(pk[i >> 1] & 0xffff);
-                            d[i] = (__mul24(lv, ls) + rnd) >> shr;
+                            d[i] = ((i & 1) ? mad_level<1>(pk[i >> 1], ls, rnd) : mad_level<0>(pk[i >> 1], ls, rnd)) >> shr;
                         }
                     }
                     if (kind == MVHP_KIND_I16x16) d[0] = dc;
@@ -334,16 +332,14 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_num_vgpr(100))) void
                     for (int i = 1; i < 16; i++) {
                         const int r = i >> 2, c = i & 3;
                         const int ls = ((r & 1) == 0 && (c & 1) == 0) ? qt.x : (((r & 1) && (c & 1)) ? qt.y : qt.z);
-                        const int lv = (i & 1) ? (pk[i >> 1] >> 16) : (int)(short)(pk[i >> 1] & 0xffff);
-                        d[i] = __mul24(lv, ls);
+                        d[i] = (i & 1) ? mad_level<1>(pk[i >> 1], ls, 0) : mad_level<0>(pk[i >> 1], ls, 0);
                     }
                 } else {
 #pragma unroll
                     for (int i = 1; i < 16; i++) {
                         const int r = i >> 2, c = i & 3;
                         const int ls = ((r & 1) == 0 && (c & 1) == 0) ? qt.x : (((r & 1) && (c & 1)) ? qt.y : qt.z);
-                        const int lv = (i & 1) ? (pk[i >> 1] >> 16) : (int)(short)(pk[i >> 1] & 0xffff);
-                        d[i] = (__mul24(lv, ls) + rnd) >> shr;
+                        d[i] = ((i & 1) ? mad_level<1>(pk[i >> 1], ls, rnd) : mad_level<0>(pk[i >> 1], ls, rnd)) >> shr;
                     }
                 }
                 d[0] = dc + 32;
