@@ -284,6 +284,12 @@ MVHP_EXPORT void mvhp_engine_destroy(mvhp_engine_t *e);
 MVHP_EXPORT int  mvhp_engine_decode(mvhp_engine_t *e, const mvhp_stream_t *s, const int *order, int n_order, int wanted,
                                     int want_rgb, mvhp_picture_sink_t sink, void *user, mvhp_decode_stats_t *stats);
 
+/* ---- memory placement (MI355X: device memory alternates, in regions of tens of GB, between two halves of the memory
+ * system; DESIGN.md 3 "Placement") ---- */
+/* Time concurrent streaming writes over two device windows of `bytes` each (both are overwritten): two windows in the
+ * same half take about twice as long per pass as two windows in different halves. */
+MVHP_EXPORT int  mvhp_probe_pair(int device, void *d_a, void *d_b, size_t bytes, int reps, float *ms_per_pass);
+
 #ifdef __cplusplus
 }
 #endif
