@@ -289,6 +289,16 @@ MVHP_EXPORT int  mvhp_engine_decode(mvhp_engine_t *e, const mvhp_stream_t *s, co
 /* Time concurrent streaming writes over two device windows of `bytes` each (both are overwritten): two windows in the
  * same half take about twice as long per pass as two windows in different halves. */
 MVHP_EXPORT int  mvhp_probe_pair(int device, void *d_a, void *d_b, size_t bytes, int reps, float *ms_per_pass);
+/* A device buffer of at least `bytes` whose 512-MB chunks come, in turn, from every part of the memory system the probe can
+ * tell apart (HIP virtual memory management): the streams of a batch then spread over the whole memory system wherever the
+ * driver happened to place them.  Meant for a few long-lived batch buffers: finding chunks of every part creates -- and
+ * releases again -- up to 200 GB of chunks on the way (about half a second).  *groups_found (may be NULL) = parts used
+ * (1: nothing to balance).  MVHP_FAILURE: no virtual memory management or not enough memory -- use an ordinary allocation. */
+MVHP_EXPORT int  mvhp_balanced_alloc(int device, size_t bytes, void **d_ptr, int *groups_found);
+/* several buffers out of ONE pass over the device memory (the pass is what takes the time) */
+MVHP_EXPORT int  mvhp_balanced_alloc_many(int device, int count, const size_t *bytes, void **d_ptrs, int *groups_found);
+MVHP_EXPORT int  mvhp_balanced_free(int device, void *d_ptr);
+MVHP_EXPORT int  mvhp_balanced_info(int device, void *d_ptr, int *chunks_per_group4, size_t *chunk_bytes);
 
 #ifdef __cplusplus
 }
