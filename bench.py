@@ -64,7 +64,9 @@ def parse_args():
                     help="pictures of the end-to-end leg, in total over the ranks (-1: 2048 per rank, or P with --strong; 0: skip)")
     ap.add_argument("--e2e-batch", type=int, default=0, help="pictures per launch in the end-to-end leg (0: engine default)")
     ap.add_argument("--placement-trials", type=int, default=3,
-                    help="N = 1 only: re-time the launch on this many re-allocated output buffers (reported, not part of value)")
+                    help="N = 1 only: re-time the launch on this many sets of ordinarily allocated buffers (reported, not part of value)")
+    ap.add_argument("--ordinary-buffers", action="store_true",
+                    help="allocate the batch buffers the ordinary way instead of mvhp_placed_alloc()")
     ap.add_argument("--host-threads", type=int, default=0, help="entropy threads per rank (0: host cores / ranks)")
     return ap.parse_args()
 
@@ -362,8 +364,34 @@ def main():
     reps = (F + d_small.shape[0] - 1) // d_small.shape[0]
     d_packed = d_small.repeat(reps, 1)[:F].contiguous()
     del d_small
-    d_yuv = torch.empty(F * params.yuv_bytes, dtype=torch.uint8, device=dev)
-    d_rgb = torch.empty(F * params.rgb_bytes, dtype=torch.uint8, device=dev) if want_rgb else None
+    # The batch's buffers come from mvhp_placed_alloc(): records, planes and RGB each in a different group of the device's
+    # memory regions (DESIGN.md 3 "Placement": the same launch takes 8.2 ms so placed and 9.6-10 ms with planes and RGB in
+    # one group; ordinary allocations land in either case by chance -- they are timed below as `placement`, for comparison).
+    # --ordinary-buffers, or an arena that cannot be had, falls back to ordinary allocations.
+    import ctypes as C
+    hipc = C.CDLL("libamdhip64.so")
+    hipc.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    placed, buffers_info = None, {"allocator": "torch.empty (hipMalloc)"}
+    if not args.ordinary_buffers:
+        from minivideo_amd import PlacedBuffers, MiniVideoError
+        try:
+            sizes = [d_packed.numel(), F * params.yuv_bytes] + ([F * params.rgb_bytes] if want_rgb else [])
+            placed = PlacedBuffers(local_rank, sizes)
+            buffers_info = {"allocator": "mvhp_placed_alloc", "groups_in_arena": placed.groups_found,
+                            "group_of_records_planes_rgb": placed.groups, "seconds": round(placed.seconds, 2)}
+        except MiniVideoError as ex:
+            buffers_info["note"] = "mvhp_placed_alloc failed (%s)" % ex
+    if placed:
+        assert hipc.hipMemcpy(placed.ptrs[0], d_packed.data_ptr(), d_packed.numel(), 3) == 0
+        p_packed, p_yuv, p_rgb = placed.ptrs[0], placed.ptrs[1], (placed.ptrs[2] if want_rgb else None)
+        torch.cuda.synchronize(dev)
+        del d_packed
+        d_packed = d_yuv = d_rgb = None
+        torch.cuda.empty_cache()
+    else:
+        d_yuv = torch.empty(F * params.yuv_bytes, dtype=torch.uint8, device=dev)
+        d_rgb = torch.empty(F * params.rgb_bytes, dtype=torch.uint8, device=dev) if want_rgb else None
+        p_packed, p_yuv, p_rgb = d_packed.data_ptr(), d_yuv.data_ptr(), (d_rgb.data_ptr() if want_rgb else None)
     torch.cuda.synchronize(dev)   # inputs are resident before anything is launched on the bench stream
     hot = HotPath(local_rank)
     if args.waves:
@@ -376,16 +404,14 @@ def main():
     stream_t = torch.cuda.Stream(device=dev)
     sp = stream_t.cuda_stream
     assert sp != 0
-    rgb_ptr = d_rgb.data_ptr() if want_rgb else None
-
     def step(ev=None):
         if ev is not None:
             ev[0].record(stream_t)
-        hot.recon_stages_dev(params, d_packed.data_ptr(), F, d_yuv.data_ptr(), rgb_ptr, sp, 3 if fused else 1)
+        hot.recon_stages_dev(params, p_packed, F, p_yuv, p_rgb, sp, 3 if fused else 1)
         if ev is not None:
             ev[1].record(stream_t)
         if want_rgb and not fused:
-            hot.recon_stages_dev(params, d_packed.data_ptr(), F, d_yuv.data_ptr(), rgb_ptr, sp, 2)
+            hot.recon_stages_dev(params, p_packed, F, p_yuv, p_rgb, sp, 2)
         if ev is not None:
             ev[2].record(stream_t)
 
@@ -428,35 +454,50 @@ def main():
         for f in sorted({0, 1, 2, 3, F // 2, F - 1} & set(range(F))):
             src = f % rec.shape[0]
             ref, ref_rgb = loader.recon(params, rec[src:src + 1], 1, want_rgb=want_rgb)
-            ok = ok and bool(np.array_equal(d_yuv[f * params.yuv_bytes:(f + 1) * params.yuv_bytes].cpu().numpy(), ref))
+            got = np.empty(params.yuv_bytes, np.uint8)
+            assert hipc.hipMemcpy(got.ctypes.data, p_yuv + f * params.yuv_bytes, params.yuv_bytes, 2) == 0
+            ok = ok and bool(np.array_equal(got, ref))
             if want_rgb:
-                ok = ok and bool(np.array_equal(d_rgb[f * params.rgb_bytes:(f + 1) * params.rgb_bytes].cpu().numpy(), ref_rgb))
-    # Where the buffers were placed moves this kernel's time by up to +-10 % ("placement"): the same launch on
-    # freshly allocated output buffers, the earlier ones kept alive so that the new ones land elsewhere.  Reported
-    # beside `value`, never part of it (the K timed steps above ran on the first allocation).
+                got = np.empty(params.rgb_bytes, np.uint8)
+                assert hipc.hipMemcpy(got.ctypes.data, p_rgb + f * params.rgb_bytes, params.rgb_bytes, 2) == 0
+                ok = ok and bool(np.array_equal(got, ref_rgb))
+    # The same launch on ORDINARY allocations, for comparison (reported beside `value`, never part of it): output buffers
+    # allocated the usual way, several times, the earlier ones kept alive so that the next ones land elsewhere.
     placement = None
-    if world == 1 and args.placement_trials > 0:
-        ms_by_alloc, hold = [ms_recon + ms_color], []
-        for _ in range(args.placement_trials):
-            hold += [d_yuv, d_rgb]
-            d_yuv = torch.empty(F * params.yuv_bytes, dtype=torch.uint8, device=dev)
-            d_rgb = torch.empty(F * params.rgb_bytes, dtype=torch.uint8, device=dev) if want_rgb else None
-            rgb_ptr = d_rgb.data_ptr() if want_rgb else None
-            torch.cuda.synchronize(dev)
-            step()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(stream_t)
-            for _ in range(5):
+    if world == 1 and args.placement_trials > 0 and placed:
+        keep = (p_packed, p_yuv, p_rgb)
+        hold, ms_by_alloc = [], []
+        try:
+            t_packed = torch.empty(mbs_per_step * 800, dtype=torch.uint8, device=dev)
+            assert hipc.hipMemcpy(t_packed.data_ptr(), p_packed, t_packed.numel(), 3) == 0
+            hold.append(t_packed)
+            for _ in range(args.placement_trials):
+                t_yuv = torch.empty(F * params.yuv_bytes, dtype=torch.uint8, device=dev)
+                t_rgb = torch.empty(F * params.rgb_bytes, dtype=torch.uint8, device=dev) if want_rgb else None
+                hold += [t_yuv, t_rgb]
+                p_packed, p_yuv, p_rgb = t_packed.data_ptr(), t_yuv.data_ptr(), (t_rgb.data_ptr() if want_rgb else None)
+                torch.cuda.synchronize(dev)
                 step()
-            e1.record(stream_t)
-            torch.cuda.synchronize(dev)
-            ms_by_alloc.append(e0.elapsed_time(e1) / 5)
-        hot.sync_check(sp)
-        placement = {"ms_per_step_by_output_allocation": [round(v, 3) for v in ms_by_alloc],
-                     "note": "first entry = the timed steps; the others = 5 launches each on re-allocated output buffers"}
-        del hold
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(stream_t)
+                for _ in range(5):
+                    step()
+                e1.record(stream_t)
+                torch.cuda.synchronize(dev)
+                ms_by_alloc.append(e0.elapsed_time(e1) / 5)
+            hot.sync_check(sp)
+        except RuntimeError:   # not enough memory beside the arena for (all of) them
+            pass
+        p_packed, p_yuv, p_rgb = keep
+        placement = {"ms_per_step_on_ordinary_allocations": [round(v, 3) for v in ms_by_alloc],
+                     "ms_per_step_timed": round(ms_recon + ms_color, 3),
+                     "note": "timed steps: buffers from mvhp_placed_alloc; the others: torch.empty (as many sets as fit beside the arena), 5 launches each"}
+        hold.clear()
+        t_packed = t_yuv = t_rgb = None
     del d_packed, d_yuv, d_rgb
     hot.close()
+    if placed:
+        placed.close()
     torch.cuda.empty_cache()
 
     # ---- end to end (stream bytes -> host planes), every rank on its share ----
@@ -518,6 +559,7 @@ def main():
                 "bit_exact_vs_oracle": ok,
             },
             "kernel_ms": {recon_name: ms_recon, "ycbcr_to_rgb_kernel": ms_color},
+            "buffers": buffers_info,
             "placement": placement,
             "host_frontend": None if host_rate is None else {
                 "macroblocks_per_s_one_thread": host_rate, "stream_bytes_per_picture": stream_bytes / n_distinct,

@@ -289,16 +289,15 @@ MVHP_EXPORT int  mvhp_engine_decode(mvhp_engine_t *e, const mvhp_stream_t *s, co
 /* Time concurrent streaming writes over two device windows of `bytes` each (both are overwritten): two windows in the
  * same half take about twice as long per pass as two windows in different halves. */
 MVHP_EXPORT int  mvhp_probe_pair(int device, void *d_a, void *d_b, size_t bytes, int reps, float *ms_per_pass);
-/* A device buffer of at least `bytes` whose 512-MB chunks come, in turn, from every part of the memory system the probe can
- * tell apart (HIP virtual memory management): the streams of a batch then spread over the whole memory system wherever the
- * driver happened to place them.  Meant for a few long-lived batch buffers: finding chunks of every part creates -- and
- * releases again -- up to 200 GB of chunks on the way (about half a second).  *groups_found (may be NULL) = parts used
- * (1: nothing to balance).  MVHP_FAILURE: no virtual memory management or not enough memory -- use an ordinary allocation. */
-MVHP_EXPORT int  mvhp_balanced_alloc(int device, size_t bytes, void **d_ptr, int *groups_found);
-/* several buffers out of ONE pass over the device memory (the pass is what takes the time) */
-MVHP_EXPORT int  mvhp_balanced_alloc_many(int device, int count, const size_t *bytes, void **d_ptrs, int *groups_found);
-MVHP_EXPORT int  mvhp_balanced_free(int device, void *d_ptr);
-MVHP_EXPORT int  mvhp_balanced_info(int device, void *d_ptr, int *chunks_per_group4, size_t *chunk_bytes);
+/* `count` (<= 8) device buffers of at least bytes[i] inside ONE allocation (arena_bytes = 0: what is free less 24 GB, at most
+ * 200 GB), placed -- as far as the arena shows several groups -- so that every buffer lies in a group of its own, the largest
+ * choosing first: records, planes and RGB of a batch in three different groups is the fastest placement there is
+ * (tools/placement_predict.py).  For long-lived batch buffers: the large allocation takes seconds (the driver clears it).
+ * groups_of[i] (may be NULL): group of buffer i, -1 = straddles; *groups_found (may be NULL): groups seen in the arena.
+ * MVHP_FAILURE: not enough memory -- use ordinary allocations. */
+MVHP_EXPORT int  mvhp_placed_alloc(int device, int count, const size_t *bytes, size_t arena_bytes, void **d_ptrs, void **arena,
+                                   int *groups_of, int *groups_found);
+MVHP_EXPORT void mvhp_placed_free(void *arena);
 
 #ifdef __cplusplus
 }

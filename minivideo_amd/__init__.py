@@ -9,6 +9,7 @@ missing, the calls raise.
 from .hotpath import (  # noqa: F401
     HotPath,
     Engine,
+    PlacedBuffers,
     StreamParams,
     MiniVideoError,
     lib,
@@ -19,4 +20,4 @@ from .hotpath import (  # noqa: F401
     UNSUPPORTED,
 )
 
-__all__ = ["HotPath", "Engine", "StreamParams", "MiniVideoError", "lib", "lib_path", "MB_BYTES"]
+__all__ = ["HotPath", "Engine", "PlacedBuffers", "StreamParams", "MiniVideoError", "lib", "lib_path", "MB_BYTES"]

@@ -188,6 +188,46 @@ class HotPath:
 
 
 # ---------------------------------------------------------------------------
+# placed batch buffers (mvhp_placed_alloc): records, planes and RGB each in a group of the memory system of its own
+# ---------------------------------------------------------------------------
+class PlacedBuffers:
+    """Device buffers of the given sizes inside one large allocation, each -- as far as the device shows several groups of
+    memory regions -- in a group of its own (DESIGN.md 3 "Placement"; the fastest placement of a batch's three streams).
+    .ptrs: device addresses; .groups: group index per buffer (-1 = straddles); .groups_found; .seconds.  close() frees all."""
+
+    def __init__(self, device, sizes, arena_bytes=0):
+        import time
+        L = lib()
+        L.mvhp_placed_alloc.restype = C.c_int
+        L.mvhp_placed_alloc.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_size_t), C.c_size_t, C.POINTER(C.c_void_p),
+                                        C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.mvhp_placed_free.restype = None
+        L.mvhp_placed_free.argtypes = [C.c_void_p]
+        n = len(sizes)
+        arr, ptrs, arena = (C.c_size_t * n)(*[int(v) for v in sizes]), (C.c_void_p * n)(), C.c_void_p()
+        gof, gf = (C.c_int * n)(), C.c_int()
+        t0 = time.perf_counter()
+        if L.mvhp_placed_alloc(int(device), n, arr, int(arena_bytes), ptrs, C.byref(arena), gof, C.byref(gf)) != SUCCESS:
+            raise MiniVideoError("mvhp_placed_alloc: not enough free device memory for the arena (use ordinary allocations)")
+        self.seconds = time.perf_counter() - t0
+        self._L, self._arena = L, arena
+        self.ptrs = [int(p) for p in ptrs]
+        self.groups = [int(g) for g in gof]
+        self.groups_found = int(gf.value)
+
+    def close(self):
+        if getattr(self, "_arena", None):
+            self._L.mvhp_placed_free(self._arena)
+            self._arena = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+# ---------------------------------------------------------------------------
 # decode engine (mvhp_engine_*): stream bytes -> reconstructed pictures, pipelined
 # ---------------------------------------------------------------------------
 class EngineOpts(C.Structure):
