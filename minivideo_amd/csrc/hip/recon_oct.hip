@@ -131,8 +131,10 @@ __global__ __launch_bounds__(NW * 64) void recon_oct_kernel(ReconArgs a)
     }
     for (int i = threadIdx.x; i < 36; i += NW * 64) B.ls8[i] = 16 * c_v8x8[i];
     for (int i = threadIdx.x; i < 64; i += NW * 64) B.qpc[i] = (uint8_t)((i < 30) ? i : c_qpc[min(i, 51) - 30]);
-    for (int i = threadIdx.x; i < 2 * 9 * 16; i += NW * 64)
-        B.tap4[i] = tap4_entry((i >> 4) % 9, i & 3, (i >> 2) & 3, i >= 9 * 16);
+    for (int i = threadIdx.x; i < 2 * 9 * 16; i += NW * 64) {   // [up-right missing][mode][lane j][upper / lower sample of the lane]
+        const int jj = (i >> 1) & 7, half = i & 1;
+        B.tap4[i] = tap4_entry((i >> 4) % 9, jj & 3, (jj >> 2) + 2 * half, i >= 9 * 16);
+    }
     for (int i = threadIdx.x; i < 9 * 64; i += NW * 64) B.tap8b[i] = tap8b_entry(i >> 6, i & 7, (i >> 3) & 7);
     if (threadIdx.x < 16) B.progress[threadIdx.x] = 0;
     if (threadIdx.x == 16) B.abort_flag = 0;
@@ -570,7 +572,7 @@ MVHP_MARK("p_i4_setup");
                 constexpr uint32_t REQ = (2u << 0) | (1u << 3) | (0u << 6) | (2u << 9) | (7u << 12) | (7u << 15) | (7u << 18) |
                                          (2u << 21) | (1u << 24);
                 // control words of blocks 2j and 2j+1, computed by lane j and broadcast inside the octet at their steps:
-                // bit 31 the mode is DC, bit 3 prediction allowed, bits 8.. tap table row offset
+                // bit 31 the mode is DC, bit 16 prediction allowed, bits 0-15 tap table row offset (bytes)
                 uint32_t info[2];
                 const uint32_t mw = (j < 2) ? m0 : (j < 4) ? m1 : (j < 6) ? m2 : m3;
 #pragma unroll
@@ -581,11 +583,11 @@ MVHP_MARK("p_i4_setup");
                     const uint32_t req = (REQ >> (min(mode, 8u) * 3)) & 7u;
                     const uint32_t ok = (((req & ~avail) == 0u) && (mode < 9u)) ? 1u : 0u; // else the prediction stays 0 (:442)
                     const uint32_t trow = (((av_upright >> b) & 1u) ? 0u : 9u) + min(mode, 8u);
-                    info[sl] = ((mode == 2u) ? 0x80000000u : 0u) | (ok << 3) | ((trow * 64u) << 8);
+                    info[sl] = ((mode == 2u) ? 0x80000000u : 0u) | (ok << 16) | (trow * 64u);
                 }
                 const int pix = (j >> 2) * 32 + (j & 3);   // the lane's upper sample inside a block, tile units (lower: +64)
                 const uint8_t *T = Q.T;
-                const uint8_t *tapb = reinterpret_cast<const uint8_t *>(B.tap4) + j * 4;
+                const uint8_t *tapb = reinterpret_cast<const uint8_t *>(B.tap4) + j * 8;   // the lane's pair of entries inside a row
                 const int32_t *res32 = reinterpret_cast<const int32_t *>(Q.res) + j;
                 // The 16 blocks run in TEN dependent steps: block (bx, by) only needs blocks decoded at bx + 2*by - 1 or
                 // earlier (left, up, up-left and -- where the standard lets it be used at all -- up-right), so the two
@@ -598,8 +600,9 @@ MVHP_MARK("p_i4_setup");
                 auto fetch = [&](const int blk) {
                     Ctl c;
                     c.inf = (uint32_t)__builtin_amdgcn_ds_bpermute(obase4 + (blk >> 1) * 4, (int)info[blk & 1]);
-                    c.ea = *reinterpret_cast<const uint32_t *>(tapb + ((c.inf >> 8) & 0xffffu));
-                    c.eb = *reinterpret_cast<const uint32_t *>(tapb + ((c.inf >> 8) & 0xffffu) + 32);
+                    const uint2 e = *reinterpret_cast<const uint2 *>(tapb + (c.inf & 0xffffu));   // one 8-byte read: upper, lower sample
+                    c.ea = e.x;
+                    c.eb = e.y;
                     c.r = res32[blk * 8];
                     return c;
                 };
@@ -607,11 +610,11 @@ MVHP_MARK("p_i4_setup");
                     const int bxO = (((blk >> 2) & 1) << 3) | ((blk & 1) << 2);
                     const int byO = ((blk >> 3) << 3) | (((blk >> 1) & 1) << 2);
                     const int base = (byO + 1) * 32 + 16 + bxO;     // tile index of the block's top-left sample
-                    const int okmask = ((int)(c.inf << 28)) >> 31;   // bit 3 -> 0 / -1
+                    const uint32_t okmask = (uint32_t)(((int)(c.inf << 15)) >> 31);   // bit 16 -> 0 / all ones
                     const int a0 = T[base - 33 + (int)(c.ea & 255)], b0 = T[base - 33 + (int)((c.ea >> 8) & 255)], c0 = T[base - 33 + (int)(c.ea >> 16)];
                     const int a1 = T[base - 33 + (int)(c.eb & 255)], b1 = T[base - 33 + (int)((c.eb >> 8) & 255)], c1 = T[base - 33 + (int)(c.eb >> 16)];
-                    int p0 = ((a0 + 2 * b0 + c0 + 2) >> 2) & okmask;
-                    int p1 = ((a1 + 2 * b1 + c1 + 2) >> 2) & okmask;
+                    // both samples in one word from here on (one mask, one select instead of two)
+                    uint32_t pp = ((uint32_t)((a0 + 2 * b0 + c0 + 2) >> 2) | ((uint32_t)((a1 + 2 * b1 + c1 + 2) >> 2) << 16)) & okmask;
                     const bool isdc = (int)c.inf < 0;
                     if (__builtin_amdgcn_ballot_w64(isdc) != 0) { // some picture predicts DC
                         // which neighbours exist is positional, i.e. the same for the eight pictures: scalar branches
@@ -626,10 +629,9 @@ MVHP_MARK("p_i4_setup");
                         } else if (bu) {
                             dcv = (sum4(*reinterpret_cast<const uint32_t *>(&T[base - 32])) + 2) >> 2;
                         }
-                        p0 = isdc ? dcv : p0;
-                        p1 = isdc ? dcv : p1;
+                        pp = isdc ? (uint32_t)dcv * 0x00010001u : pp;
                     }
-                    return sat_pk_u8(pk_add_sat(p0 | (p1 << 16), c.r));
+                    return sat_pk_u8(pk_add_sat((int)pp, c.r));
                 };
                 auto put = [&](const int blk, const uint32_t two) {
                     const int bxO = (((blk >> 2) & 1) << 3) | ((blk & 1) << 2);
