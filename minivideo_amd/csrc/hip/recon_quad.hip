@@ -495,7 +495,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_num_vgpr(100))) void
                 constexpr uint32_t REQ = (2u << 0) | (1u << 3) | (0u << 6) | (2u << 9) | (7u << 12) | (7u << 15) | (7u << 18) |
                                          (2u << 21) | (1u << 24);
                 // control word of block j, computed by lane j and broadcast inside the quarter at step j:
-                // bits 0-1 left/up available, bit 2 mode is DC, bit 3 prediction allowed, bits 8.. tap table row offset
+                // (control word, below: bit 31 the mode is DC, bit 16 prediction allowed, bits 0-15 tap table row offset)
                 uint32_t info;
                 {
                     const uint32_t mw = (j < 4) ? m0 : (j < 8) ? m1 : (j < 12) ? m2 : m3;
@@ -504,8 +504,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_num_vgpr(100))) void
                     const uint32_t req = (REQ >> (min(mode, 8u) * 3)) & 7u;
                     const uint32_t ok = (((req & ~avail) == 0u) && (mode < 9u)) ? 1u : 0u; // else the prediction stays 0 (:442)
                     const uint32_t trow = (((av_upright >> j) & 1u) ? 0u : 9u) + min(mode, 8u);
-                    // bit 31: the mode is DC; bit 3: prediction allowed; bits 8..: tap table row offset
-                    info = ((mode == 2u) ? 0x80000000u : 0u) | (ok << 3) | ((trow * 64u) << 8);
+                    info = ((mode == 2u) ? 0x80000000u : 0u) | (ok << 16) | (trow * 64u);   // bit 31 DC, bit 16 allowed, bits 0-15 table row offset
                 }
                 const int pix = (j >> 2) * 32 + (j & 3);   // this lane's sample inside a block, tile units
                 const uint8_t *T = Q.T;
@@ -515,7 +514,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_num_vgpr(100))) void
                 const int qbase4 = (lane & 48) << 2;
                 __builtin_amdgcn_s_setprio(MVHP_CHAIN_PRIO);   // the dependent chain issues few, latency-critical instructions
                 uint32_t inf = quarter_bcast(info, qbase4, 0);
-                uint32_t e_nx = *reinterpret_cast<const uint32_t *>(tapb + ((inf >> 8) & 0xffffu));
+                uint32_t e_nx = *reinterpret_cast<const uint32_t *>(tapb + (inf & 0xffffu));
                 int r_nx = (int)Q.res[j];
 #pragma unroll
                 for (int blk = 0; blk < 16; blk++) {
@@ -527,10 +526,10 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_num_vgpr(100))) void
                     const int r = r_nx;
                     if (blk < 15) {
                         inf = quarter_bcast(info, qbase4, blk + 1);
-                        e_nx = *reinterpret_cast<const uint32_t *>(tapb + ((inf >> 8) & 0xffffu));
+                        e_nx = *reinterpret_cast<const uint32_t *>(tapb + (inf & 0xffffu));
                         r_nx = (int)Q.res[(blk + 1) * 16 + j];
                     }
-                    const int okmask = ((int)(cur << 28)) >> 31;   // bit 3 -> 0 / -1
+                    const int okmask = ((int)(cur << 15)) >> 31;   // bit 16 -> 0 / -1
                     const int ta = T[base - 33 + (int)(e & 255)];
                     const int tb = T[base - 33 + (int)((e >> 8) & 255)];
                     const int tc = T[base - 33 + (int)(e >> 16)];
