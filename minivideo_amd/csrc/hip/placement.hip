@@ -132,34 +132,106 @@ MVHP_EXPORT int mvhp_placed_alloc(int device, int count, const size_t *bytes, si
         for (size_t b = 0; b < nb; b++) fprintf(stderr, " %c", 'A' + group[b]);
         fprintf(stderr, "\n");
     }
-    // the largest buffers choose first: the longest free run of a group nobody has taken yet, else of any group, else any run
-    std::vector<int> order((size_t)count);
-    for (int i = 0; i < count; i++) order[(size_t)i] = i;
-    std::sort(order.begin(), order.end(), [&](int x, int y) { return bytes[x] > bytes[y]; });
-    std::vector<char> taken(nb, 0);
-    std::vector<char> group_used(8, 0);
-    bool ok = true;
-    for (int oi = 0; oi < count && ok; oi++) {
-        const int i = order[(size_t)oi];
-        const size_t want = nblk[(size_t)i];
-        long best_start = -1;
-        int best_rank = 99, best_group = -1;
-        for (size_t s = 0; s + want <= nb; s++) {
-            bool free_run = true, one_group = true;
-            for (size_t k = 0; k < want; k++) {
-                if (taken[s + k]) { free_run = false; break; }
-                if (group[s + k] != group[s]) one_group = false;
-            }
-            if (!free_run) continue;
-            const int rank = one_group ? (group_used[(size_t)group[s]] ? 1 : 0) : 2;
-            if (rank < best_rank) { best_rank = rank; best_start = (long)s; best_group = one_group ? group[s] : -1; }
-            if (rank == 0) break;
+    // Placement.  The labels above come from single probes against one representative per group and can be off by a block or
+    // two (some groups differ by less than others: runs like B B B C B B C B are seen), so the choice is MEASURED: one
+    // candidate run per group and buffer size, every pair of candidate windows probed, and the assignment of distinct
+    // groups to the buffers with the smallest sum of pair times (= the least shared memory system) wins.  With fewer groups
+    // than buffers, or no room, the greedy rule decides: the largest buffers choose first -- a free run of a group nobody has
+    // taken yet, else of any one group, else any run.
+    const int G = (int)reps.size();
+    auto run_start = [&](int g, size_t want, const std::vector<char> &taken_) -> long {
+        for (size_t s0 = 0; s0 + want <= nb; s0++) {
+            bool okrun = true;
+            for (size_t k = 0; k < want && okrun; k++) okrun = !taken_[s0 + k] && group[s0 + k] == g;
+            if (okrun) return (long)s0;
         }
-        if (best_start < 0) { ok = false; break; }
-        for (size_t k = 0; k < want; k++) taken[(size_t)best_start + k] = 1;
-        if (best_group >= 0) group_used[(size_t)best_group] = 1;
-        out[i] = at((size_t)best_start, 0);
-        if (groups_of) groups_of[i] = best_group;
+        return -1;
+    };
+    std::vector<char> taken(nb, 0);
+    bool placed_all = false;
+    if (G >= count && count <= 4) {
+        // candidate start of buffer i in group g
+        std::vector<std::vector<long>> cand((size_t)count, std::vector<long>((size_t)G, -1));
+        for (int i = 0; i < count; i++)
+            for (int g = 0; g < G; g++) cand[(size_t)i][(size_t)g] = run_start(g, nblk[(size_t)i], taken);
+        // pair times between the groups' windows (the window of a group = the start of its longest candidate)
+        std::vector<long> win((size_t)G, -1);
+        for (int g = 0; g < G; g++)
+            for (int i = 0; i < count; i++)
+                if (cand[(size_t)i][(size_t)g] >= 0 && win[(size_t)g] < 0) win[(size_t)g] = cand[(size_t)i][(size_t)g];
+        std::vector<std::vector<float>> pt((size_t)G, std::vector<float>((size_t)G, 0.f));
+        for (int x = 0; x < G; x++)
+            for (int y = x + 1; y < G; y++)
+                if (win[(size_t)x] >= 0 && win[(size_t)y] >= 0) {
+                    const float t = std::min(pair_ms(device, at((size_t)win[(size_t)x], 0), at((size_t)win[(size_t)y], 0)),
+                                             pair_ms(device, at((size_t)win[(size_t)x], kWindow), at((size_t)win[(size_t)y], kWindow)));
+                    pt[(size_t)x][(size_t)y] = pt[(size_t)y][(size_t)x] = t;
+                }
+        std::vector<int> pick((size_t)count, -1), best_pick;
+        float best_score = 1e30f;
+        std::vector<char> used((size_t)G, 0);
+        // depth-first over the buffers: a different group for each
+        auto rec = [&](auto &&self, int i, float score) -> void {
+            if (score >= best_score) return;
+            if (i == count) { best_score = score; best_pick = pick; return; }
+            for (int g = 0; g < G; g++) {
+                if (used[(size_t)g] || cand[(size_t)i][(size_t)g] < 0) continue;
+                float add = 0.f;
+                for (int k = 0; k < i; k++) add += pt[(size_t)pick[(size_t)k]][(size_t)g];
+                used[(size_t)g] = 1;
+                pick[(size_t)i] = g;
+                self(self, i + 1, score + add);
+                used[(size_t)g] = 0;
+            }
+        };
+        rec(rec, 0, 0.f);
+        if (!best_pick.empty()) {
+            for (int i = 0; i < count; i++) {
+                const int g = best_pick[(size_t)i];
+                const long s0 = cand[(size_t)i][(size_t)g];
+                for (size_t k = 0; k < nblk[(size_t)i]; k++) taken[(size_t)s0 + k] = 1;
+                out[i] = at((size_t)s0, 0);
+                if (groups_of) groups_of[i] = g;
+            }
+            placed_all = true;
+            if (getenv("MVHP_PLACEMENT_TRACE")) {
+                fprintf(stderr, "placement: pair times between the groups' windows (ms):");
+                for (int x = 0; x < G; x++)
+                    for (int y = x + 1; y < G; y++) fprintf(stderr, " %c%c %.3f", 'A' + x, 'A' + y, pt[(size_t)x][(size_t)y]);
+                fprintf(stderr, "; chosen:");
+                for (int i = 0; i < count; i++) fprintf(stderr, " %c", 'A' + best_pick[(size_t)i]);
+                fprintf(stderr, " (sum %.3f)\n", best_score);
+            }
+        }
+    }
+    bool ok = true;
+    if (!placed_all) {
+        std::vector<int> order((size_t)count);
+        for (int i = 0; i < count; i++) order[(size_t)i] = i;
+        std::sort(order.begin(), order.end(), [&](int x, int y) { return bytes[x] > bytes[y]; });
+        std::vector<char> group_used(8, 0);
+        for (int oi = 0; oi < count && ok; oi++) {
+            const int i = order[(size_t)oi];
+            const size_t want = nblk[(size_t)i];
+            long best_start = -1;
+            int best_rank = 99, best_group = -1;
+            for (size_t s0 = 0; s0 + want <= nb; s0++) {
+                bool free_run = true, one_group = true;
+                for (size_t k = 0; k < want; k++) {
+                    if (taken[s0 + k]) { free_run = false; break; }
+                    if (group[s0 + k] != group[s0]) one_group = false;
+                }
+                if (!free_run) continue;
+                const int rank = one_group ? (group_used[(size_t)group[s0]] ? 1 : 0) : 2;
+                if (rank < best_rank) { best_rank = rank; best_start = (long)s0; best_group = one_group ? group[s0] : -1; }
+                if (rank == 0) break;
+            }
+            if (best_start < 0) { ok = false; break; }
+            for (size_t k = 0; k < want; k++) taken[(size_t)best_start + k] = 1;
+            if (best_group >= 0) group_used[(size_t)best_group] = 1;
+            out[i] = at((size_t)best_start, 0);
+            if (groups_of) groups_of[i] = best_group;
+        }
     }
     if (!ok) { (void)hipFree(base); return MVHP_FAILURE; }
     if (groups_found) *groups_found = (int)reps.size();
