@@ -208,6 +208,16 @@ def cpu_baseline(params, stream, n_distinct, rec, want_rgb, budget_s):
     return out
 
 
+def all_ranks_ok(ok, world, dist, dev):
+    """MIN over the ranks of a per-rank verdict (a mismatch on a rank other than 0 must not pass silently)."""
+    if world <= 1:
+        return bool(ok)
+    import torch
+    t = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cpu" if dist.get_backend() == "gloo" else dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return bool(t.item())
+
+
 def end_to_end(args, params, stream, n_distinct, rec, want_rgb, total, rank, world, local_rank, dist, dev):
     """stream bytes in host memory -> planes (+ RGB) in page-locked host memory, through the pipeline
     behind minivideo_decode.  Every rank decodes its share of the pictures with its own engine on its own GPU."""
@@ -252,12 +262,12 @@ def end_to_end(args, params, stream, n_distinct, rec, want_rgb, total, rank, wor
     eng.close()
     L.mvhp_stream_close(h)
     ok = rc == 1 and st["pictures_ok"] == len(order)
-    if rank == 0:
-        from oracle import loader
-        for seq, (idr, yuv, rgb) in kept.items():
-            ref, ref_rgb = loader.recon(params, rec[idr % n_distinct], 1, want_rgb=want_rgb)
-            ok = ok and bool(np.array_equal(yuv, ref)) and (not want_rgb or bool(np.array_equal(rgb, ref_rgb)))
-        ok = ok and len(kept) == len(check)
+    from oracle import loader   # every rank checks its own pictures (each rank decodes a stream of its own seed)
+    for seq, (idr, yuv, rgb) in kept.items():
+        ref, ref_rgb = loader.recon(params, rec[idr % n_distinct], 1, want_rgb=want_rgb)
+        ok = ok and bool(np.array_equal(yuv, ref)) and (not want_rgb or bool(np.array_equal(rgb, ref_rgb)))
+    ok = ok and len(kept) == len(check)
+    ok = all_ranks_ok(ok, world, dist, dev)
     w = st["wall_s"]
     stages = {
         "entropy_decode_host": {"busy_s": st["entropy_busy_s"], "threads": st["host_threads"],
@@ -447,20 +457,20 @@ def main():
     value = total_frames * params.mbs * args.steps / elapsed
 
     # spot-check pictures of the last step against the oracle (bit-exact) -- the checker, not the product
-    ok = None
-    if rank == 0:
-        from oracle import loader
-        ok = True
-        for f in sorted({0, 1, 2, 3, F // 2, F - 1} & set(range(F))):
-            src = f % rec.shape[0]
-            ref, ref_rgb = loader.recon(params, rec[src:src + 1], 1, want_rgb=want_rgb)
-            got = np.empty(params.yuv_bytes, np.uint8)
-            assert hipc.hipMemcpy(got.ctypes.data, p_yuv + f * params.yuv_bytes, params.yuv_bytes, 2) == 0
-            ok = ok and bool(np.array_equal(got, ref))
-            if want_rgb:
-                got = np.empty(params.rgb_bytes, np.uint8)
-                assert hipc.hipMemcpy(got.ctypes.data, p_rgb + f * params.rgb_bytes, params.rgb_bytes, 2) == 0
-                ok = ok and bool(np.array_equal(got, ref_rgb))
+    # (every rank checks its own batch; the verdicts are reduced with MIN so that a mismatch on any rank fails the run)
+    from oracle import loader
+    ok = True
+    for f in sorted({0, 1, 2, 3, F // 2, F - 1} & set(range(F))):
+        src = f % rec.shape[0]
+        ref, ref_rgb = loader.recon(params, rec[src:src + 1], 1, want_rgb=want_rgb)
+        got = np.empty(params.yuv_bytes, np.uint8)
+        assert hipc.hipMemcpy(got.ctypes.data, p_yuv + f * params.yuv_bytes, params.yuv_bytes, 2) == 0
+        ok = ok and bool(np.array_equal(got, ref))
+        if want_rgb:
+            got = np.empty(params.rgb_bytes, np.uint8)
+            assert hipc.hipMemcpy(got.ctypes.data, p_rgb + f * params.rgb_bytes, params.rgb_bytes, 2) == 0
+            ok = ok and bool(np.array_equal(got, ref_rgb))
+    ok = all_ranks_ok(ok, world, dist, dev)
     # The same launch on ORDINARY allocations, for comparison (reported beside `value`, never part of it): output buffers
     # allocated the usual way, several times, the earlier ones kept alive so that the next ones land elsewhere.
     placement = None
@@ -591,7 +601,7 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-    if ok is False or (e2e is not None and rank == 0 and not e2e["bit_exact_vs_oracle"]):
+    if ok is False or (e2e is not None and not e2e["bit_exact_vs_oracle"]):
         raise SystemExit("bench: GPU output differs from the oracle")
 
 

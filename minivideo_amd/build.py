@@ -39,7 +39,8 @@ def build_product(force=False):
     host_src = sorted(glob.glob(os.path.join(CSRC, "host", "*.cpp")))
     hdrs = (glob.glob(os.path.join(CSRC, "*", "*.h")) + glob.glob(os.path.join(CSRC, "*", "*.hpp"))
             + glob.glob(os.path.join(CSRC, "*", "*.inc")) + glob.glob(os.path.join(ROOT, "include", "*.h")))
-    if not force and not _newer(LIB, hip_src + host_src + hdrs):
+    checker = os.path.join(ROOT, "tools", "check_prefetch_hazard.py")
+    if not force and not _newer(LIB, hip_src + host_src + hdrs + [checker]):
         return LIB
     inc = ["-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(CSRC, "hip"), "-I" + os.path.join(CSRC, "host")]
     objdir = os.path.join(PKG, "build")
@@ -62,7 +63,9 @@ def build_product(force=False):
         tmpd = os.path.join(objdir, "temps_" + base)
         asm = os.path.join(tmpd, base + "-hip-amdgcn-amd-amdhsa-gfx950.s")
         need_asm = base in checked
-        if force or _newer(o, [s] + hdrs) or (need_asm and not os.path.exists(asm)):
+        # (the checked objects also depend on the checker's rules: a changed rule re-checks objects already built)
+        deps = [s] + hdrs + ([check_prefetch_hazard.__file__] if need_asm else [])
+        if force or _newer(o, deps) or (need_asm and not os.path.exists(asm)):
             cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wno-unused-value"]
             if need_asm:
                 os.makedirs(tmpd, exist_ok=True)

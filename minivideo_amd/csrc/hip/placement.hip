@@ -41,20 +41,23 @@ MVHP_EXPORT int mvhp_probe_pair(int device, void *a, void *b, size_t bytes, int 
 {
     if (!a || !b || bytes < 4096 || reps <= 0 || !ms) return MVHP_FAILURE;
     if (hipSetDevice(device) != hipSuccess) return MVHP_FAILURE;
-    static thread_local hipEvent_t e0 = nullptr, e1 = nullptr;
-    static thread_local int ev_device = -1;
-    if (ev_device != device) {
-        if (e0) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); e0 = e1 = nullptr; }
-        if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return MVHP_FAILURE;
-        ev_device = device;
-    }
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (hipEventCreate(&e0) != hipSuccess) return MVHP_FAILURE;
+    if (hipEventCreate(&e1) != hipSuccess) { (void)hipEventDestroy(e0); return MVHP_FAILURE; }
     const size_t n16 = bytes / 16;
+    bool ok = true;
     hipLaunchKernelGGL(pair_write_kernel, dim3(2048), dim3(256), 0, 0, (uint4 *)a, (uint4 *)b, n16, 0u);   // warm
-    (void)hipEventRecord(e0, 0);
-    for (int r = 0; r < reps; r++)
+    ok = ok && hipGetLastError() == hipSuccess;
+    ok = ok && hipEventRecord(e0, 0) == hipSuccess;
+    for (int r = 0; r < reps && ok; r++) {
         hipLaunchKernelGGL(pair_write_kernel, dim3(2048), dim3(256), 0, 0, (uint4 *)a, (uint4 *)b, n16, (uint32_t)r);
-    (void)hipEventRecord(e1, 0);
-    if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(ms, e0, e1) != hipSuccess) return MVHP_FAILURE;
+        ok = hipGetLastError() == hipSuccess;   // a refused launch would leave the two events microseconds apart: a "time" all the same
+    }
+    ok = ok && hipEventRecord(e1, 0) == hipSuccess;
+    ok = ok && hipEventSynchronize(e1) == hipSuccess && hipEventElapsedTime(ms, e0, e1) == hipSuccess;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (!ok) { (void)hipGetLastError(); return MVHP_FAILURE; }
     *ms /= (float)reps;
     return MVHP_SUCCESS;
 }
@@ -72,12 +75,17 @@ struct Arena {
 };
 constexpr size_t kBlock = (size_t)4 << 30, kWindow = (size_t)1 << 30;
 
-float pair_ms(int device, void *a, void *b)
-{
-    float ms = 0.f;
-    if (mvhp_probe_pair(device, a, b, kWindow, 2, &ms) != MVHP_SUCCESS) return -1.f;
-    return ms;
-}
+// a probe that fails makes every later comparison meaningless: remembered in `failed`, checked before anything is placed
+struct Probe {
+    int device;
+    bool failed = false;
+    float operator()(void *a, void *b)
+    {
+        float ms = 0.f;
+        if (failed || mvhp_probe_pair(device, a, b, kWindow, 2, &ms) != MVHP_SUCCESS || !(ms > 0.f)) { failed = true; return 0.f; }
+        return ms;
+    }
+};
 
 } // namespace
 
@@ -109,6 +117,8 @@ MVHP_EXPORT int mvhp_placed_alloc(int device, int count, const size_t *bytes, si
     if (hipMalloc(&base, arena_bytes) != hipSuccess) { (void)hipGetLastError(); return MVHP_FAILURE; }
     const size_t nb = arena_bytes / kBlock;
     auto at = [&](size_t blk, size_t off) { return (void *)((uint8_t *)base + blk * kBlock + off); };
+    Probe probe{device};
+    auto pair_ms = [&](int, void *a, void *b) { return probe(a, b); };
     // "same group" = a window against its neighbour inside one block (median over up to seven blocks)
     std::vector<float> cal;
     for (size_t b = 0; b < nb && cal.size() < 7; b += std::max<size_t>(1, nb / 7)) cal.push_back(pair_ms(device, at(b, 0), at(b, kWindow)));
@@ -127,6 +137,10 @@ MVHP_EXPORT int mvhp_placed_alloc(int device, int count, const size_t *bytes, si
         else if (reps.size() < 6) { group[b] = (int)reps.size(); reps.push_back(b); }
         else group[b] = best < 0 ? 0 : best;
     }
+    // a failed probe (launch refused, event error) must not be read as a time -- the classification and the measured
+    // assignment below would be made on meaningless numbers and still be reported as a placement.  Callers fall back to
+    // ordinary allocations on MVHP_FAILURE.
+    if (probe.failed) { (void)hipFree(base); return MVHP_FAILURE; }
     if (getenv("MVHP_PLACEMENT_TRACE")) {
         fprintf(stderr, "placement: arena %.0f GB, same-group pair %.3f ms, groups per 4 GB:", arena_bytes / 1073741824.0, t_same);
         for (size_t b = 0; b < nb; b++) fprintf(stderr, " %c", 'A' + group[b]);
@@ -185,6 +199,7 @@ MVHP_EXPORT int mvhp_placed_alloc(int device, int count, const size_t *bytes, si
             }
         };
         rec(rec, 0, 0.f);
+        if (probe.failed) { (void)hipFree(base); return MVHP_FAILURE; }
         if (!best_pick.empty()) {
             for (int i = 0; i < count; i++) {
                 const int g = best_pick[(size_t)i];

@@ -272,7 +272,7 @@ bool Engine::init(const mvhp_engine_opts_t *opts, std::string &err)
         ctx_[k].dev = api_.ctx_create(ctx_[k].device, err);
         if (!ctx_[k].dev) return false;
     }
-    // device memory one batch may take: half of what is free now, split over the two batch buffers of every context
+    // device memory one batch may take: half of what is free now, split over the three batch buffers (filling / in the kernel / downloading) of every context
     // that shares the device
     for (int k = 0; k < n_ctx; k++) {
         int sharers = 0;
@@ -442,7 +442,9 @@ void Engine::feeder()
             l.unlock();
             have_mem = grow(c->buf, (size_t)C * pic_bytes);
             l.lock();
-            rg = retry_q_.empty() ? nullptr : &retry_q_.front();   // (the deque may have grown meanwhile; its front is the same group)
+            // `rg` is NOT fetched again: a group another context pushed meanwhile waits for the next iteration (`avail` and
+            // `n` were sized without it), and push_back keeps references to a deque's elements valid -- only this
+            // thread pops
         }
         if (!have_mem) {   // no page-locked memory: these pictures fail
             free_in_.push_back(c);

@@ -5,7 +5,7 @@
 // -> macroblock loop h264_slice.c:1046-1139 -> export_idr export.c:618-767.
 //
 // The engine is plain C++ over a small table of device operations (DeviceApi), so that the threading can be built and
-// checked on a CPU-only box against a stub device (tests/test_engine_tsan.py); the product's table is HIP
+// checked on a CPU-only box against a stub device (tools/engine_harness.cpp, tests/test_engine_harness.py: ThreadSanitizer + AddressSanitizer); the product's table is HIP
 // (csrc/hip/hotpath_abi.hip) and there is no CPU implementation of it in the library.
 #pragma once
 #include <stddef.h>

@@ -38,6 +38,7 @@ using mvengine::DevCtx;
 std::atomic<int> g_recon_calls{0}, g_live_ctx{0};
 std::atomic<long> g_dev_allocs{0};
 int g_devices = 2;
+std::atomic<int> g_slow_host_alloc_us{0};   // page-locking is slow on a real box: the feeder drops its lock around it
 
 uint64_t checksum(const uint8_t *p, size_t n)
 {
@@ -47,7 +48,11 @@ uint64_t checksum(const uint8_t *p, size_t n)
 }
 
 int stub_device_count() { return g_devices; }
-void *stub_host_alloc(size_t n) { return malloc(n ? n : 1); }
+void *stub_host_alloc(size_t n)
+{
+    if (g_slow_host_alloc_us > 0) std::this_thread::sleep_for(std::chrono::microseconds(g_slow_host_alloc_us.load()));
+    return malloc(n ? n : 1);
+}
 void stub_host_free(void *p) { free(p); }
 DevCtx *stub_ctx_create(int device, std::string &) { g_live_ctx++; return new DevCtx{device}; }
 void stub_ctx_destroy(DevCtx *c) { g_live_ctx--; delete c; }
@@ -223,6 +228,21 @@ int main(int argc, char **argv)
         Check c; mvhp_decode_stats_t st;
         EXPECT(run("fail/1ctx", o, all, n_idr, false, c, st) == MVHP_SUCCESS);
         EXPECT(c.bad == 0 && c.failed == 5 && c.ok == n_idr - 5 && st.batches_requeued == 0);
+    }
+    {   // ADVICE r2 (feeder race): a re-queued group arrives while the feeder has dropped its lock to page-lock a LARGER chunk
+        // than the group holds (batches ramp 64 -> 128 -> 256, the chunk buffers regrow with them, the stub's page-locking
+        // takes 30 ms, the first 64-picture batch fails on context 0 meanwhile).  The feeder must finish the chunk it was
+        // sizing from the ordinary list and take the group on its next iteration; indexing the group with that chunk's
+        // count read past its vector (AddressSanitizer) and delivered pictures twice / never.
+        std::vector<int> order;
+        for (int k = 0; k < 700; k++) order.push_back(k % n_idr);
+        mvhp_engine_opts_t o = base; o.contexts = 2; o.chunk_pictures = 256; o.fail_context = 0;
+        Check c; mvhp_decode_stats_t st;
+        g_slow_host_alloc_us = 30000;
+        EXPECT(run("requeue during page-lock", o, order, (int)order.size(), false, c, st) == MVHP_SUCCESS);
+        g_slow_host_alloc_us = 0;
+        EXPECT(c.bad == 0 && c.ok == (int)order.size() && c.failed == 0 && st.batches_requeued == 1);
+        EXPECT((int)st.pictures_issued > (int)order.size());   // the failed batch's pictures were entropy-decoded twice
     }
     {   // the sink stops the decode
         mvhp_engine_opts_t o = base; o.contexts = 2; o.chunk_pictures = 2; o.batch_pictures = 4;
