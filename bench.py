@@ -53,6 +53,9 @@ def parse_args():
     ap.add_argument("--source", default="stream", choices=["stream", "records"],
                     help="stream: synthetic Annex-B stream -> host front end -> packed records (default); "
                          "records: random packed records drawn directly (minivideo_amd.synth)")
+    ap.add_argument("--kinds", default="", metavar="P16,P8",
+                    help="with --source records: P(Intra16x16), P(Intra8x8 | not Intra16x16) instead of the profile's mix "
+                         "(content ablations: which macroblock kinds cost what; never a BASELINE.json configuration)")
     ap.add_argument("--waves", type=int, default=0)
     ap.add_argument("--layout", default="auto", choices=["auto", "rows", "quad", "oct"],
                     help="pictures per workgroup: rows = 1 (one wavefront per macroblock row), quad = 4, oct = 8")
@@ -366,8 +369,9 @@ def main():
         stream_bytes = int(stream.size)
     else:
         from minivideo_amd.synth import synth_packed
+        kinds = tuple(float(v) for v in args.kinds.split(",")) if args.kinds else None
         params, rec = synth_packed(args.width_mbs, args.height_mbs, n_distinct, seed=1000 + rank,
-                                   profile=args.profile, density=args.density)
+                                   profile=args.profile, density=args.density, kinds=kinds, qp_range=(24, 32))
         stream_bytes = None
     dev = torch.device("cuda", local_rank)
     d_small = torch.from_numpy(rec.reshape(rec.shape[0], -1)).to(dev)
@@ -527,7 +531,7 @@ def main():
             achieved = mbs_per_step * BYTES_PER_MB_COLOR / (ms_color * 1e-3) / 1e9
             kname = "ycbcr_to_rgb_kernel"
         traffic, traffic_src = measured_traffic(args, fused, kname, F)
-        is_cfg = args.width_mbs == 120 and args.height_mbs == 68 and args.density == "dense"
+        is_cfg = args.width_mbs == 120 and args.height_mbs == 68 and args.density == "dense" and not args.kinds
         if args.strong and is_cfg and args.profile == "baseline":
             cfg = f"BASELINE.json configs[4]: {args.strong} independent 1080p IDR pictures per step sharded over {world} GPU(s)"
         elif is_cfg and args.profile == "baseline":

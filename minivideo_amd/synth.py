@@ -52,8 +52,9 @@ def _nxn_allowed(left, up, upleft, illegal):
 
 
 def synth_packed(width_mbs, height_mbs, n_frames, seed=1, profile="baseline", density="dense",
-                 qp_range=(20, 40), cqp_offsets=(0, 0), illegal_modes=False, allow_qp36_i16=False):
-    """Returns (StreamParams, packed[n_frames, W*H, 800] uint8)."""
+                 qp_range=(20, 40), cqp_offsets=(0, 0), illegal_modes=False, allow_qp36_i16=False, kinds=None):
+    """Returns (StreamParams, packed[n_frames, W*H, 800] uint8).
+    kinds = (P(Intra16x16), P(Intra8x8 | not Intra16x16)) overrides the profile's mix (measurement aid: content ablations)."""
     rng = np.random.default_rng(seed)
     W, H, F = int(width_mbs), int(height_mbs), int(n_frames)
     N = W * H
@@ -62,7 +63,11 @@ def synth_packed(width_mbs, height_mbs, n_frames, seed=1, profile="baseline", de
 
     # ---- macroblock kinds ----
     u = rng.random((F, N))
-    if density == "light":
+    if kinds is not None:
+        kind = np.where(u < kinds[0], KIND_I16x16, KIND_I4x4)
+        v = rng.random((F, N))
+        kind = np.where((kind == KIND_I4x4) & (v < kinds[1]), KIND_I8x8, kind)
+    elif density == "light":
         kind = np.where(u < 0.5, KIND_I16x16, KIND_I4x4)
     else:
         kind = np.where(u < 0.4, KIND_I16x16, KIND_I4x4)
