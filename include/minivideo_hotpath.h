@@ -69,6 +69,13 @@ extern "C" {
 #define MVHP_KIND_I4x4   0
 #define MVHP_KIND_I8x8   1
 #define MVHP_KIND_I16x16 2
+/* I_PCM (h264_macroblock.c:151-154 returns UNSUPPORTED, ipcm_construction_process h264_intra_prediction.c:2585-2630 is dead
+ * code in the reference): only streams opened with MVHP_STREAM_SPEC produce it (outside parity).  The
+ * coefficient area then holds the 384 SAMPLES, one byte each, arranged so that every owner of a 32-byte piece of the record
+ * finds whole rows in it: for j = 0..7, bytes [64j, 64j+32) = luma rows 2j and 2j+1 (16 samples each), bytes [64j+32, 64j+40) =
+ * Cb row j, [64j+40, 64j+48) = Cr row j, [64j+48, 64j+64) = 0; the chroma part of the area (bytes 512..767) is 0.
+ * nz_mask = 0, qp_y = 0 (QP'Y of an I_PCM macroblock, 7.4.5). */
+#define MVHP_KIND_IPCM   3
 
 typedef struct mvhp_mb_header {
     uint8_t  mb_kind;          /* MVHP_KIND_*  (MbPartPredMode, h264_macroblock_struct.h:33-44) */
@@ -77,7 +84,10 @@ typedef struct mvhp_mb_header {
     uint8_t  chroma_pred_mode; /* IntraChromaPredMode 0=DC 1=H 2=V 3=Plane                      */
     uint8_t  i16_pred_mode;    /* Intra16x16PredMode 0=V 1=H 2=DC 3=Plane                       */
     uint8_t  flags;            /* reserved (TransformBypassModeFlag is never set for 8-bit)     */
-    uint16_t reserved0;
+    uint8_t  unavail;          /* MVHP_UNAVAIL_*: neighbouring macroblocks that exist by geometry but lie in ANOTHER SLICE
+                                  (6.4.8: not available); always 0 for the reference's one-slice pictures -- set only by
+                                  streams opened with MVHP_STREAM_SPEC, announced by MVHP_PARAM_SLICES   */
+    uint8_t  reserved0;
     uint32_t nz_mask;          /* bit b (0-15): luma 4x4 block b (or 8x8 block b>>2) has a
                                   non-zero level; bit 16+k: Cb block k; bit 20+k: Cr block k.
                                   DC levels count for the block whose slot 0 they occupy.
@@ -85,6 +95,11 @@ typedef struct mvhp_mb_header {
     uint8_t  pred_mode[16];    /* final Intra4x4PredMode[16] or Intra8x8PredMode[4]             */
     uint32_t reserved1;
 } mvhp_mb_header_t;
+
+#define MVHP_UNAVAIL_A 1u   /* left        (mbAddrA, h264_spatial.c:333-416) */
+#define MVHP_UNAVAIL_B 2u   /* above       (mbAddrB) */
+#define MVHP_UNAVAIL_C 4u   /* above right (mbAddrC) */
+#define MVHP_UNAVAIL_D 8u   /* above left  (mbAddrD) */
 
 /* ---------------------------------------------------------------------------
  * Compact pictures: the transfer format between the host front end and the GPU (PCIe carries it instead of the packed
@@ -109,7 +124,13 @@ typedef struct mvhp_stream_params {
     uint32_t height_mbs;                     /* PicHeightInMapUnits (frame MBs only)   */
     int32_t  chroma_qp_index_offset;         /* PPS, Cb (h264_transform.c:611-618)     */
     int32_t  second_chroma_qp_index_offset;  /* PPS, Cr                                */
-    uint32_t flags;                          /* MVHP_PARAM_* hints (speed only)        */
+    uint32_t flags;                          /* MVHP_PARAM_*                            */
+    /* MVHP_PARAM_SCALING only (ignored otherwise): the weight matrices in force for the batch's pictures, after the
+     * fall-back rules of 7.4.2.1.1 / 7.4.2.2 (h264_parameterset.c:723-736, 904-923 parse them; the reference's own LevelScale
+     * is only right for flat lists), in RASTER order [i*4+j] / [i*8+j]: LevelScale4x4[plane][m][i][j] =
+     * scaling4[plane][i*4+j] * normAdjust4x4(m,i,j) (h264_transform.c:645-741). */
+    uint8_t  scaling4[3][16];                /* Intra Y, Cb, Cr                          */
+    uint8_t  scaling8[64];                   /* Intra Y 8x8                              */
 } mvhp_stream_params_t;
 
 /* flags: the batch may contain Intra8x8 macroblocks (PPS transform_8x8_mode_flag).  A hint for the kernel choice
@@ -120,6 +141,14 @@ typedef struct mvhp_stream_params {
  * differ from the reference exactly on Intra16x16 macroblocks at QP'Y = 36.  Set by streams opened with
  * MVHP_STREAM_SPEC (outside the parity contract, opt-in). */
 #define MVHP_PARAM_SPEC_LUMA_DC 2u
+/* flags (set only for streams opened with MVHP_STREAM_SPEC; outside the parity contract -- the reference
+ * decodes none of these correctly):
+ * MVHP_PARAM_SLICES   pictures of several slices: records carry mvhp_mb_header_t::unavail.  Reconstructed by the one-picture-
+ *                     per-workgroup kernel, where availability is a per-wavefront scalar (the batch kernels keep eight / four
+ *                     pictures in lock step at one macroblock position and derive availability from the position alone).
+ * MVHP_PARAM_SCALING  scaling4 / scaling8 hold non-flat weight matrices (SPS / PPS scaling lists).  Same kernel. */
+#define MVHP_PARAM_SLICES  4u
+#define MVHP_PARAM_SCALING 8u
 
 /* Bytes of one reconstructed picture: planar Y | Cb | Cr of the *uncropped*
  * coded size (export.c:80-81), and interleaved RGB8. */
@@ -139,7 +168,8 @@ MVHP_EXPORT int  mvhp_stream_open(const uint8_t *data, size_t size, mvhp_stream_
  * chosen by minivideo_decode when the environment has MINIVIDEO_SPEC=1): index the stream the way the standard
  * defines it instead of the way esparser.c:40-143 does -- three-byte start codes (Annex B), slice / SPS / PPS NAL units
  * of any nal_ref_idc, no 32-byte blind tail -- and reconstruct Intra16x16 at QP'Y = 36 by the standard's rule
- * (MVHP_PARAM_SPEC_LUMA_DC).  Still one slice per picture: a picture of several slices is refused. */
+ * (MVHP_PARAM_SPEC_LUMA_DC); pictures of several slices (MVHP_PARAM_SLICES), SPS / PPS scaling lists (MVHP_PARAM_SCALING) and
+ * I_PCM macroblocks (MVHP_KIND_IPCM) are decoded by the standard's rules. */
 #define MVHP_STREAM_SPEC 1u
 MVHP_EXPORT int  mvhp_stream_open_ex(const uint8_t *data, size_t size, uint32_t flags, mvhp_stream_t **out);
 /* Same for an ISO-BMFF (MP4/MOV) buffer: avcC parameter sets + the IDR NAL units of the sync samples of the first

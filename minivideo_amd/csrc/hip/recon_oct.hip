@@ -94,7 +94,30 @@ __device__ __forceinline__ uint32_t lerp_u8(uint32_t a, uint32_t b, uint32_t c) 
 #define MVHP_PRAGMA_(x) _Pragma(#x)
 #define MVHP_UNROLL(n) MVHP_PRAGMA_(unroll n)
 
-#ifdef MVHP_MARKS   // measurement builds: section markers that survive into the ISA text (tools/isa_sections.py)
+#if defined(MVHP_STAMPS)
+// Measurement build (tools/stamp_profile.py; results differ in timing only): the shader clock at every section boundary,
+// the elapsed cycles added to the accumulator of the boundary that ENDS the interval -- so the interval that ends at mark
+// "x_end" is the body of x, the one that ends at a begin mark is what ran since the previous mark.  Accumulators are 32-bit
+// scalars (a launch is ~2*10^7 cycles); the s_memtime result is waited for with lgkmcnt(0), which also drains the wave's
+// LDS queue at every boundary: sections are charged their own LDS latency, not their successors'.
+constexpr const char *kStampNames[] = {"prefetch_wait", "header", "resid_luma", "r_8x8", "r_8x8_end", "r_4x4_dc", "r_4x4", "r_4x4_end",
+                                       "resid_store", "resid_chroma", "wait_up", "wait_up_end", "pred_chroma", "pred_luma", "p_i16",
+                                       "p_i16_end", "p_i4_setup", "p_i4_chain", "p_i4_end", "p_i8", "p_i8_end", "writeout",
+                                       "wo_flush_setup", "wo_planes", "wo_rgb", "wo_short", "wo_park", "wo_end", "neighbours", "publish",
+                                       "step_end"};
+constexpr int kStampCount = sizeof(kStampNames) / sizeof(kStampNames[0]);
+constexpr bool stamp_streq(const char *a, const char *b) { while (*a && *a == *b) { ++a; ++b; } return *a == *b; }
+constexpr int stamp_id(const char *n) { for (int i = 0; i < kStampCount; i++) if (stamp_streq(kStampNames[i], n)) return i; return -1; }
+__device__ uint32_t g_stamps[256 * 8 * 32];   // [workgroup < 256][wave < 8][boundary < 32] cycles, summed over the launch
+#define MVHP_MARK(name)                                                                           \
+    do {                                                                                          \
+        constexpr int id_ = stamp_id(name);                                                       \
+        static_assert(id_ >= 0, "unknown stamp");                                                 \
+        const uint32_t t_ = (uint32_t)__builtin_amdgcn_s_memtime();                               \
+        st_acc[id_] += t_ - st_prev;                                                              \
+        st_prev = t_;                                                                             \
+    } while (0)
+#elif defined(MVHP_MARKS)   // measurement builds: section markers that survive into the ISA text (tools/isa_sections.py)
 #define MVHP_MARK(name) asm volatile("; MARK " name ::: "memory")
 #else
 #define MVHP_MARK(name)
@@ -193,6 +216,12 @@ __global__ __launch_bounds__(NW * 64) void recon_oct_kernel(ReconArgs a)
     const int up_adj = __builtin_amdgcn_readfirstlane((wave == 0) ? -1 : 0); // wave 0 follows the last wave's previous pass
     int done = 0;  // macroblocks completed by this wave
     int n_st = 0;  // asm stores the previous step issued behind its prefetch (0 also when the compiler counted them)
+#if defined(MVHP_STAMPS)
+    uint32_t st_acc[kStampCount];
+#pragma unroll
+    for (int i = 0; i < kStampCount; i++) st_acc[i] = 0;
+    uint32_t st_prev = (uint32_t)__builtin_amdgcn_s_memtime();
+#endif
     // output strip (see the write-out): the luma rows this lane owns of "its" macroblock of the strip; chroma rows wait in LDS (Q.SC)
     v4i L0 = {0, 0, 0, 0}, L1 = L0, L2 = L0, L3 = L0, L4 = L0, L5 = L0, L6 = L0, L7 = L0;
 
@@ -320,6 +349,7 @@ MVHP_MARK("r_8x8");
                             *reinterpret_cast<int2 *>(dst + i * 8) = make_int2(pack_res_shr6(colv[0][i], colv[1][i]),
                                                                                pack_res_shr6(colv[2][i], colv[3][i]));
                     }
+MVHP_MARK("r_8x8_end");
                 } else {
                     // ---- luma 4x4 (transform_4x4_residual, h264_transform.c:1049-1191), two blocks per lane ----
 MVHP_MARK("r_4x4_dc");
@@ -378,6 +408,7 @@ MVHP_MARK("r_4x4");
 #pragma unroll
                         for (int i = 0; i < 8; i++) { r2[0][i] = 0; r2[1][i] = 0; }
                     }
+MVHP_MARK("r_4x4_end");
                 }
             }
             MVHP_MARK("resid_store");
@@ -441,6 +472,7 @@ MVHP_MARK("r_4x4");
                     }
                 }
                 asm volatile("" ::: "memory");
+                MVHP_MARK("wait_up_end");
                 // ten dwords per picture: lanes 0-3 luma top, 4-5 luma up-right (when C), 6-7 Cb top; then lanes 0-1 Cr top
                 if (C || (j >> 1) != 2) {
                     uint8_t *dst;
@@ -557,6 +589,7 @@ MVHP_MARK("p_i16");
                 }
                 emit_block_ypairs(&Q.T[(yO + 1) * 32 + 16 + xO0], 32, pw[0], r2[0]);
                 emit_block_ypairs(&Q.T[(yO + 1) * 32 + 16 + xO0 + 4], 32, pw[1], r2[1]);
+MVHP_MARK("p_i16_end");
             } else if (kind == MVHP_KIND_I4x4) {
                 // Intra 4x4: 16 dependent block steps; lane j predicts samples (j&3, j>>2) and (j&3, (j>>2)+2) of the block.
                 // h264_intra_prediction.c:161-177, :315-483, :496-960 + transform4x4_luma (h264_transform.c:121-156).
@@ -657,6 +690,7 @@ MVHP_MARK("p_i4_chain");
                     WAVE_SYNC();
                 }
                 __builtin_amdgcn_s_setprio(0);
+MVHP_MARK("p_i4_end");
             } else {
                 // Intra 8x8: h264_intra_prediction.c:1107-1353 (edge filter) + :1366-1793 + transform8x8_luma;
                 // lane j predicts row j of the block
@@ -754,6 +788,7 @@ MVHP_MARK("p_i8");
                     }
                     WAVE_SYNC();
                 }
+MVHP_MARK("p_i8_end");
             }
             WAVE_SYNC();
 
@@ -777,6 +812,7 @@ MVHP_MARK("p_i8");
                     L6 = *reinterpret_cast<const v4i *>(t0 + 12 * 32);  L7 = *reinterpret_cast<const v4i *>(t0 + 13 * 32);
                 }
                 if (mbi == 3 || mbx == W - 1) {
+                    MVHP_MARK("wo_flush_setup");
                     uint32_t qmb_v = qmb;
                     asm volatile("" : "+v"(qmb_v));
                     // chroma rows 2i + h of the lane's macroblock: parked ones from the strip, the current one from the tile
@@ -798,6 +834,7 @@ MVHP_MARK("p_i8");
 #define MVHP_ST(ADDR, DATA, BASE, OFF) MVHP_ST_(ADDR, DATA, BASE, OFF)
 #define MVHP_ST_(ADDR, DATA, BASE, OFF) asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 offset:" #OFF MVHP_STORE_HINT "\n\ts_nop 1" : : "v"(ADDR), "v"(DATA), "s"(BASE) : "memory")
 #define MVHP_ST2(ADDR, DATA, BASE) asm volatile("s_nop 4\n\tglobal_store_dwordx2 %0, %1, %2" MVHP_STORE_HINT : : "v"(ADDR), "v"(DATA), "s"(BASE) : "memory")
+                        MVHP_MARK("wo_planes");
                         if (valid) {
                             MVHP_ST(pl, L0, gyuv, 0);            MVHP_ST(pl + pitch, L1, gyuv, 0);
                             MVHP_ST(pl + p4, L2, gyuv, 0);       MVHP_ST(pl + p4 + pitch, L3, gyuv, 0);
@@ -811,6 +848,7 @@ MVHP_MARK("p_i8");
                             MVHP_ST2(pcb + 3 * c2, b3, gyuv);   MVHP_ST2(pcr + 3 * c2, q3, gyuv);
                         }
                         if (RGB) {
+                            MVHP_MARK("wo_rgb");
                             const uint32_t prgb = ORGB + lrow * 3u;
                             // a row pair of the lane's macroblock against the chroma row it shares (export_utils.c:278-279)
 #define MVHP_RGB_OUT(YQA, YQB, CB, CR, I)                                                                              \
@@ -838,6 +876,7 @@ MVHP_MARK("p_i8");
 #undef MVHP_ST2
                         n_st = VM_STRIP;
                     } else if (m_own <= mbi && valid) {
+                        MVHP_MARK("wo_short");
                         // ---- short strip at the right picture edge (W % 4 != 0): compiler-counted stores ----
                         const v4i Lr[8] = {L0, L1, L2, L3, L4, L5, L6, L7};
                         const uint2 cbr[4] = {cb0, cb1, cb2, cb3}, crr[4] = {cr0, cr1, cr2, cr3};
@@ -861,6 +900,7 @@ MVHP_MARK("p_i8");
                         }
                     }
                 } else {
+                    MVHP_MARK("wo_park");
                     // ---- park the chroma rows (lane j: row j of both planes) in the LDS strip ----
                     const uint2 cvb = *reinterpret_cast<const uint2 *>(&Q.TC[0][(j + 1) * 16 + 8]);
                     const uint2 cvr = *reinterpret_cast<const uint2 *>(&Q.TC[1][(j + 1) * 16 + 8]);
@@ -872,6 +912,7 @@ MVHP_MARK("p_i8");
             // =====================================================================================
             // neighbour state for the next macroblock / next row, then publish
             // =====================================================================================
+            MVHP_MARK("wo_end");
             MVHP_MARK("neighbours");
             {
                 // left columns: lane j luma rows j, j+8 and chroma row j of both planes; corners (old top-right sample) by
@@ -907,13 +948,30 @@ MVHP_MARK("p_i8");
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             if (lane == 0) __hip_atomic_store(&B.progress[wave], done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             WAVE_SYNC();
+            MVHP_MARK("step_end");
         }
     }
+#if defined(MVHP_STAMPS)
+    if (lane_c == 0 && blockIdx.x < 256 && wave < 8) {
+#pragma unroll
+        for (int i = 0; i < kStampCount; i++) g_stamps[((int)blockIdx.x * 8 + wave) * 32 + i] = st_acc[i];
+    }
+#endif
 }
 
 #undef OPACKED
 #undef OYUV
 #undef ORGB
+
+#if defined(MVHP_STAMPS)
+extern "C" __attribute__((visibility("default"))) int mvhp_debug_read_stamps(uint32_t *out, const char **names, int *count)
+{
+    if (count) *count = kStampCount;
+    if (names) for (int i = 0; i < kStampCount; i++) names[i] = kStampNames[i];
+    if (!out) return 1;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(uint32_t) * 256 * 8 * 32) == hipSuccess ? 1 : 0;
+}
+#endif
 
 size_t recon_oct_lds_bytes(int width_mbs, int nw)
 {

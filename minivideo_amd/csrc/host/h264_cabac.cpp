@@ -47,6 +47,16 @@ void CabacEngine::init(int slice_qp)
     refill();
 }
 
+size_t CabacEngine::standard_bit_position() const { return pd_.br_.pos() - (size_t)k_; }
+
+void CabacEngine::restart()
+{
+    range_ = 510;
+    val_ = pd_.br_.bits(9);
+    k_ = 0;
+    refill();
+}
+
 bool CabacEngine::overrun() const { return pd_.br_.pos() > pd_.br_.size_bits() + (size_t)k_; }
 
 void CabacEngine::refill()
@@ -132,7 +142,7 @@ unsigned CabacEngine::coded_block_pattern(int addr)
 int CabacEngine::mb_qp_delta(int addr)
 {
     int inc = 0;
-    if (addr > 0) {
+    if (addr > pd_.slice_first_) {   // the previous macroblock in decoding order of THIS slice
         const MbState &p = pd_.mbs_[addr - 1];
         const bool no_residual = (p.kind != MVHP_KIND_I16x16) && p.cbp_luma == 0 && p.cbp_chroma == 0;
         inc = (!no_residual && p.qp_delta_nonzero) ? 1 : 0;
@@ -156,6 +166,7 @@ int CabacEngine::cbf_ctx_inc(int addr, int cat, int blkIdx) const
     int condA, condB;
     auto mb_cond = [&](int n, int bit, bool applicable) -> int {
         if (n < 0) return 1;               // unavailable, current MB is intra
+        if (pd_.mbs_[n].kind == MVHP_KIND_IPCM) return 1;   // mb_type I_PCM: condTermFlagN = 1 (spec mode only)
         if (!applicable) return 0;         // transBlockN not assigned
         return (pd_.mbs_[n].cbf >> bit) & 1;
     };

@@ -71,6 +71,11 @@ struct CabacEngine {
         return 0;
     }
 
+    // I_PCM (9.3.1.2): where the standard's 9-bit register stands in the slice data (the bit reader runs k_ bits ahead of
+    // it), and a fresh start of the arithmetic decoder behind the samples with the context variables kept
+    size_t standard_bit_position() const;
+    void   restart();
+
     unsigned mb_type(int addr);
     int      transform_size_8x8_flag(int addr);
     int      prev_intra_pred_mode_flag();

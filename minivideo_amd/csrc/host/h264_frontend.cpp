@@ -123,7 +123,98 @@ static bool is_frext_profile(int p)
     return p == 100 || p == 110 || p == 122 || p == 244 || p == 44 || p == 83 || p == 86 || p == 118 || p == 128;
 }
 
-int parse_sps(BitReader &br, Sps &s, std::string &err)
+// scaling_list(), 7.3.2.1.1.1 (the reference's scaling_list_4x4 / _8x8, h264_parameterset.c:723-775, parse the same syntax
+// but store into sps_array[0] and apply no fall-back rule)
+static void parse_scaling_list(BitReader &br, uint8_t *list, int size, uint8_t *state)
+{
+    int last = 8, next = 8;
+    bool use_default = false;
+    for (int j = 0; j < size; j++) {
+        if (next != 0) {
+            const int delta = br.se();
+            next = (last + delta + 256) % 256;
+            use_default = (j == 0 && next == 0);
+        }
+        list[j] = (uint8_t)(next == 0 ? last : next);
+        last = list[j];
+    }
+    *state = use_default ? 2 : 1;
+}
+
+static void parse_scaling_matrix(BitReader &br, ScalingLists &sl, int n_lists)
+{
+    sl.present = true;
+    for (int i = 0; i < n_lists; i++) {
+        sl.state[i] = 0;
+        if (!br.bit()) continue;   // seq_ / pic_scaling_list_present_flag[i]
+        if (i < 6) parse_scaling_list(br, sl.l4[i], 16, &sl.state[i]);
+        else parse_scaling_list(br, sl.l8[i - 6], 64, &sl.state[i]);
+    }
+}
+
+// Tables 7-3 / 7-4 (zig-zag order, like the transmitted lists)
+static const uint8_t kDefault4x4Intra[16] = {6, 13, 13, 20, 20, 20, 28, 28, 28, 28, 32, 32, 32, 37, 37, 42};
+static const uint8_t kDefault4x4Inter[16] = {10, 14, 14, 20, 20, 20, 24, 24, 24, 24, 27, 27, 27, 30, 30, 34};
+static const uint8_t kDefault8x8Intra[64] = {6,  10, 10, 13, 11, 13, 16, 16, 16, 16, 18, 18, 18, 18, 18, 23, 23, 23, 23, 23, 23, 25,
+                                             25, 25, 25, 25, 25, 25, 27, 27, 27, 27, 27, 27, 27, 27, 29, 29, 29, 29, 29, 29, 29, 31,
+                                             31, 31, 31, 31, 31, 33, 33, 33, 33, 33, 36, 36, 36, 36, 38, 38, 38, 40, 40, 42};
+static const uint8_t kDefault8x8Inter[64] = {9,  13, 13, 15, 13, 15, 17, 17, 17, 17, 19, 19, 19, 19, 19, 21, 21, 21, 21, 21, 21, 22,
+                                             22, 22, 22, 22, 22, 22, 24, 24, 24, 24, 24, 24, 24, 24, 25, 25, 25, 25, 25, 25, 25, 27,
+                                             27, 27, 27, 27, 27, 28, 28, 28, 28, 28, 30, 30, 30, 30, 32, 32, 32, 33, 33, 35};
+
+// One level of the hierarchy: the eight lists (zig-zag) that result from `sl` with fall-back rule set A (`base` = nullptr: the
+// defaults of Table 7-2) or set B (`base` = the sequence-level lists).
+static void resolve_lists(const ScalingLists &sl, const uint8_t (*base4)[16], const uint8_t (*base8)[64], uint8_t out4[6][16],
+                          uint8_t out8[2][64])
+{
+    for (int i = 0; i < 6; i++) {
+        const uint8_t *def = (i < 3) ? kDefault4x4Intra : kDefault4x4Inter;
+        const uint8_t *src;
+        if (sl.state[i] == 1) src = sl.l4[i];
+        else if (sl.state[i] == 2) src = def;
+        else if (i == 0 || i == 3) src = base4 ? base4[i] : def;   // rule A: the default; rule B: the sequence-level list
+        else src = out4[i - 1];                                     // both rules: the previous list of the same level
+        memcpy(out4[i], src, 16);
+    }
+    for (int i = 0; i < 2; i++) {
+        const uint8_t *def = i ? kDefault8x8Inter : kDefault8x8Intra;
+        const uint8_t *src;
+        if (sl.state[6 + i] == 1) src = sl.l8[i];
+        else if (sl.state[6 + i] == 2) src = def;
+        else src = base8 ? base8[i] : def;
+        memcpy(out8[i], src, 64);
+    }
+}
+
+bool effective_intra_scaling(const ScalingLists &sps, const ScalingLists &pps, bool transform8x8, uint8_t w4[3][16], uint8_t w8[64])
+{
+    uint8_t s4[6][16], s8[2][64], p4[6][16], p8[2][64];
+    if (sps.present) resolve_lists(sps, nullptr, nullptr, s4, s8);
+    else { memset(s4, 16, sizeof(s4)); memset(s8, 16, sizeof(s8)); }   // Flat_4x4_16 / Flat_8x8_16
+    if (pps.present) {
+        ScalingLists pl = pps;
+        if (!transform8x8) pl.state[6] = pl.state[7] = 0;   // the 8x8 lists are only transmitted with transform_8x8_mode_flag
+        // 7.4.2.2: set A when the SPS carries no matrix, else set B
+        if (sps.present) resolve_lists(pl, s4, s8, p4, p8);
+        else resolve_lists(pl, nullptr, nullptr, p4, p8);
+    } else {
+        memcpy(p4, s4, sizeof(p4));
+        memcpy(p8, s8, sizeof(p8));
+    }
+    bool nonflat = false;
+    for (int pl = 0; pl < 3; pl++)
+        for (int k = 0; k < 16; k++) {
+            w4[pl][kZigzag4x4[k]] = p4[pl][k];   // zig-zag position k -> raster slot (frame scan, Table 8-13 / utils.h:64)
+            nonflat |= p4[pl][k] != 16;
+        }
+    for (int k = 0; k < 64; k++) {
+        w8[kZigzag8x8[k]] = p8[0][k];
+        nonflat |= p8[0][k] != 16;
+    }
+    return nonflat;
+}
+
+int parse_sps(BitReader &br, Sps &s, std::string &err, bool spec)
 {
     s = Sps();
     s.profile_idc = (int)br.bits(8);
@@ -138,7 +229,12 @@ int parse_sps(BitReader &br, Sps &s, std::string &err)
         const unsigned bdl = br.ue(), bdc = br.ue();
         if (bdl != 0 || bdc != 0) { err = "SPS: only 8-bit samples are supported"; return RC_UNSUPPORTED; }
         s.qpprime_y_zero_transform_bypass = br.bit();
-        if (br.bit()) { err = "SPS: scaling matrices are not supported"; return RC_UNSUPPORTED; } // SURVEY 8b envelope
+        if (br.bit()) {   // seq_scaling_matrix_present_flag
+            // reference envelope: its lists have no fall-back rule and land in sps_array[0] -- refused; by the
+            // standard (MVHP_STREAM_SPEC): parsed, h264_parameterset.c:723-736 is the syntax
+            if (!spec) { err = "SPS: scaling matrices are not supported"; return RC_UNSUPPORTED; }
+            parse_scaling_matrix(br, s.scaling, 8);
+        }
     }
     // h264_parameterset.c:458-465: only Baseline(66), Main(77), High(100)
     if (s.profile_idc != 66 && s.profile_idc != 77 && s.profile_idc != 100) {
@@ -182,7 +278,7 @@ int parse_sps(BitReader &br, Sps &s, std::string &err)
     return RC_SUCCESS;
 }
 
-int parse_pps(BitReader &br, const Sps *sps_table, Pps &p, std::string &err)
+int parse_pps(BitReader &br, const Sps *sps_table, Pps &p, std::string &err, bool spec)
 {
     p = Pps();
     p.pps_id = (int)br.ue();
@@ -207,7 +303,10 @@ int parse_pps(BitReader &br, const Sps *sps_table, Pps &p, std::string &err)
     // h264_parameterset.c:898: extension read when more_rbsp_data() && profile_idc >= 100
     if (br.more_rbsp_data() && s.profile_idc >= 100) {
         p.transform_8x8_mode = br.bit();
-        if (br.bit()) { err = "PPS: scaling matrices are not supported"; return RC_UNSUPPORTED; } // :904-923
+        if (br.bit()) {   // pic_scaling_matrix_present_flag (:904-923: the reference answers UNSUPPORTED)
+            if (!spec) { err = "PPS: scaling matrices are not supported"; return RC_UNSUPPORTED; }
+            parse_scaling_matrix(br, p.scaling, 6 + (p.transform_8x8_mode ? 2 : 0));
+        }
         p.second_chroma_qp_index_offset = br.se();
     } else {
         p.second_chroma_qp_index_offset = p.chroma_qp_index_offset;
@@ -225,41 +324,54 @@ int parse_pps(BitReader &br, const Sps *sps_table, Pps &p, std::string &err)
 // ---------------------------------------------------------------------------
 // picture decoder
 // ---------------------------------------------------------------------------
-PictureDecoder::PictureDecoder(const Sps &sps, const Pps &pps, int nal_ref_idc)
-    : sps_(sps), pps_(pps), nal_ref_idc_(nal_ref_idc), W_(sps.width_mbs), H_(sps.height_map_units)
+PictureDecoder::PictureDecoder(const Sps &sps, const Pps &pps, int nal_ref_idc, bool spec)
+    : sps_(sps), pps_(pps), nal_ref_idc_(nal_ref_idc), W_(sps.width_mbs), H_(sps.height_map_units), spec_(spec)
 {
 }
 
 PictureDecoder::~PictureDecoder() { delete cabac_; }
 
-int PictureDecoder::run(std::string &err)
+int PictureDecoder::run(const SliceRbsp *slices, int n_slices, std::string &err)
 {
     mbs_.assign((size_t)W_ * H_, MbState());
     level_overflow_ = false;
-    int rc = slice_header(err);
-    if (rc != RC_SUCCESS) return rc;
-    rc = slice_data(err);
-    if (rc != RC_SUCCESS) return rc;
+    next_addr_ = 0;
+    multi_slice_ = n_slices > 1;
+    for (int k = 0; k < n_slices; k++) {
+        br_ = BitReader(slices[k].rbsp, slices[k].n);
+        nal_ref_idc_ = slices[k].nal_ref_idc;
+        int rc = slice_header(err);
+        if (rc != RC_SUCCESS) return rc;
+        rc = slice_data(err);
+        if (rc != RC_SUCCESS) return rc;
+    }
+    if (next_addr_ != W_ * H_) { err = "the slices of the picture do not cover it"; return RC_FAILURE; }
     if (level_overflow_) { err = "transform coefficient level outside int16"; return RC_FAILURE; }
     return RC_SUCCESS;
 }
 
-int PictureDecoder::decode(const uint8_t *rbsp, size_t n, uint8_t *packed, size_t packed_bytes, std::string &err)
+int PictureDecoder::decode_slices(const SliceRbsp *slices, int n_slices, uint8_t *packed, size_t packed_bytes, std::string &err)
 {
     if ((size_t)W_ * H_ * MVHP_MB_BYTES != packed_bytes) { err = "packed buffer size mismatch"; return RC_FAILURE; }
-    br_ = BitReader(rbsp, n);
+    if (n_slices < 1) { err = "no slice"; return RC_FAILURE; }
     out_ = packed;   // (every record is zeroed right before its macroblock is parsed: macroblock())
     compact_ = false;
-    const int rc = run(err);
+    const int rc = run(slices, n_slices, err);
     if (rc != RC_SUCCESS) memset(out_, 0, packed_bytes);   // the records behind a failure were never written: no stale bytes
     return rc;
 }
 
-int PictureDecoder::decode_compact(const uint8_t *rbsp, size_t n, uint8_t *buf, size_t cap, size_t *used, std::string &err)
+int PictureDecoder::decode(const uint8_t *rbsp, size_t n, uint8_t *packed, size_t packed_bytes, std::string &err)
+{
+    const SliceRbsp one{rbsp, n, nal_ref_idc_};
+    return decode_slices(&one, 1, packed, packed_bytes, err);
+}
+
+int PictureDecoder::decode_slices_compact(const SliceRbsp *slices, int n_slices, uint8_t *buf, size_t cap, size_t *used, std::string &err)
 {
     const size_t mbs = (size_t)W_ * H_;
     if (cap < mbs * MVHP_COMPACT_MB_BYTES_MAX + MVHP_COMPACT_SLACK_BYTES) { err = "compact buffer too small"; return RC_FAILURE; }
-    br_ = BitReader(rbsp, n);
+    if (n_slices < 1) { err = "no slice"; return RC_FAILURE; }
     out_ = nullptr;
     compact_ = true;
     mb_off_ = reinterpret_cast<uint32_t *>(buf);
@@ -269,15 +381,27 @@ int PictureDecoder::decode_compact(const uint8_t *rbsp, size_t n, uint8_t *buf, 
         const int v = atoi(e);
         if (v >= 0 && v < MVHP_COMPACT_MAX_ENTRIES) compact_max_ = (uint32_t)v;
     }
-    const int rc = run(err);
+    const int rc = run(slices, n_slices, err);
     if (used) *used = rc == RC_SUCCESS ? (size_t)(cw_ - buf) : 0;
     return rc;
+}
+
+int PictureDecoder::decode_compact(const uint8_t *rbsp, size_t n, uint8_t *buf, size_t cap, size_t *used, std::string &err)
+{
+    const SliceRbsp one{rbsp, n, nal_ref_idc_};
+    return decode_slices_compact(&one, 1, buf, cap, used, err);
 }
 
 // H6: decodeSliceHeader, h264_slice.c:156-334 (IDR / I slices only)
 int PictureDecoder::slice_header(std::string &err)
 {
-    br_.ue();                                  // first_mb_in_slice: ignored, the MB loop starts at 0 (:1019)
+    const unsigned first_mb = br_.ue();        // first_mb_in_slice: the reference ignores it, its MB loop starts at 0 (:1019)
+    if (spec_) {                               // by the standard: the slice starts there; slices arrive in macroblock order
+        if ((int)first_mb != next_addr_) { err = "slice does not start where the previous one ended (arbitrary slice order is not supported)"; return RC_FAILURE; }
+        slice_first_ = (int)first_mb;
+    } else {
+        slice_first_ = 0;
+    }
     const unsigned slice_type = br_.ue();
     br_.ue();                                  // pic_parameter_set_id (resolved by the caller)
     if (slice_type != 2 && slice_type != 7) { err = "slice: IDR slice_type must be I (2 or 7)"; return RC_FAILURE; }
@@ -321,22 +445,33 @@ int PictureDecoder::slice_data(std::string &err)
         cabac_ = new CabacEngine(*this);
         cabac_->init(slice_qp_);
     }
-    cur_x_ = 0;
-    for (int addr = 0; addr < n_mbs; addr++) {
+    cur_x_ = slice_first_ % W_;
+    int addr = slice_first_;
+    for (; addr < n_mbs; addr++) {
         cur_addr_ = addr;
-        curA_ = cur_x_ > 0 ? addr - 1 : -1;
+        curA_ = (cur_x_ > 0 && addr - 1 >= slice_first_) ? addr - 1 : -1;
         int rc = macroblock(addr, err);
         if (++cur_x_ == W_) cur_x_ = 0;
         if (rc != RC_SUCCESS) return rc;
         if (pps_.entropy_coding_mode) {
             const int end = cabac_->decode_terminate();
             if (end) {
-                if (addr != n_mbs - 1) { err = "slice ends before the last macroblock (one slice per picture only)"; return RC_FAILURE; }
+                // Reference mode: a slice that ends before the last macroblock fails the picture (the reference leaves its loop
+                // with SUCCESS there and exports a picture with holes, h264_slice.c:1047-1139 -- documented divergence).
+                // By the standard (spec mode) the next slice NAL of the picture continues at addr + 1.
+                if (!spec_ && addr != n_mbs - 1) { err = "slice ends before the last macroblock (one slice per picture only)"; return RC_FAILURE; }
+                addr++;
                 break;
             }
+            if (cabac_->overrun()) { err = "slice data truncated"; return RC_FAILURE; }
+        } else {
+            if (br_.overrun()) { err = "slice data truncated"; return RC_FAILURE; }
+            // CAVLC: the reference's more_rbsp_data() is true to the very end of its sample (H12), its loop ends with the
+            // picture; by the standard the slice ends where its data does
+            if (spec_ && !br_.more_rbsp_data()) { addr++; break; }
         }
-        if (pps_.entropy_coding_mode ? cabac_->overrun() : br_.overrun()) { err = "slice data truncated"; return RC_FAILURE; }
     }
+    next_addr_ = addr;
     return RC_SUCCESS;
 }
 
@@ -406,6 +541,74 @@ void PictureDecoder::derive_pred_modes(int addr, const uint8_t prev_flag[16], co
     }
 }
 
+// MVHP_UNAVAIL_*: neighbours that geometry has but that belong to an earlier slice (6.4.8; h264_spatial.c:333-416 knows
+// one slice only).  0 for every macroblock of a one-slice picture.
+uint8_t PictureDecoder::unavail_bits(int addr) const
+{
+    if (slice_first_ == 0) return 0;
+    const bool hasA = cur_x_ > 0, hasB = addr >= W_, hasC = hasB && cur_x_ < W_ - 1, hasD = hasA && hasB;
+    // (cur_x_ is the column of `addr`: called before slice_data advances it)
+    uint8_t u = 0;
+    if (hasA && addr - 1 < slice_first_) u |= MVHP_UNAVAIL_A;
+    if (hasB && addr - W_ < slice_first_) u |= MVHP_UNAVAIL_B;
+    if (hasC && addr - W_ + 1 < slice_first_) u |= MVHP_UNAVAIL_C;
+    if (hasD && addr - W_ - 1 < slice_first_) u |= MVHP_UNAVAIL_D;
+    return u;
+}
+
+// I_PCM (mb_type 25, spec mode only): pcm_alignment_zero_bits, then 256 + 2 * 64 samples of 8 bits (7.3.5).  Under CABAC
+// the arithmetic decoder has just decoded the terminate bin (9.3.1.2): the samples start at the next byte boundary behind
+// the last bit the standard's 9-bit register has read, and the engine is initialised again behind them (contexts kept).
+// Neighbour state (what later macroblocks derive from this one): nC = 16 (9.2.1), coded_block_flag = 1 (9.3.3.1.1.9),
+// CodedBlockPattern read as 47, intra_chroma_pred_mode 0, mb_qp_delta 0 -- QP'Y carries over unchanged (7.4.5).
+int PictureDecoder::pcm_samples(int addr, std::string &err)
+{
+    MbState &mb = mbs_[addr];
+    if (pps_.entropy_coding_mode) br_.seek(cabac_->standard_bit_position());
+    while (!br_.byte_aligned()) {
+        if (br_.bit() != 0) { err = "pcm_alignment_zero_bit is 1"; return RC_FAILURE; }
+    }
+    if (br_.bits_left() < 384 * 8) { err = "I_PCM samples truncated"; return RC_FAILURE; }
+    const uint8_t *smp = br_.data() + (br_.pos() >> 3);   // 256 luma (raster), 64 Cb, 64 Cr
+    br_.skip(384 * 8);
+    if (pps_.entropy_coding_mode) cabac_->restart();
+    mb = MbState();
+    mb.kind = MVHP_KIND_IPCM;
+    mb.mb_type = 25;
+    mb.cbp_luma = 15;
+    mb.cbp_chroma = 2;
+    memset(mb.tc_luma, 16, sizeof(mb.tc_luma));
+    memset(mb.tc_c, 16, sizeof(mb.tc_c));
+    mb.cbf = 0x7ffffffu;
+    for (int b = 0; b < 16; b++) mb.pred[b] = 2;
+    // the record: header + the samples in the layout of MVHP_KIND_IPCM (include/minivideo_hotpath.h)
+    uint8_t area[MVHP_MB_COEFS * 2];
+    memset(area, 0, sizeof(area));
+    for (int j = 0; j < 8; j++) {
+        memcpy(area + 64 * j, smp + 32 * j, 32);             // luma rows 2j, 2j+1
+        memcpy(area + 64 * j + 32, smp + 256 + 8 * j, 8);    // Cb row j
+        memcpy(area + 64 * j + 40, smp + 320 + 8 * j, 8);    // Cr row j
+    }
+    mvhp_mb_header_t h;
+    memset(&h, 0, sizeof(h));
+    h.mb_kind = MVHP_KIND_IPCM;
+    h.qp_y = (uint8_t)qp_prev_;
+    h.unavail = unavail_bits(addr);
+    if (!compact_) {
+        uint8_t *rec = out_ + (size_t)addr * MVHP_MB_BYTES;
+        memcpy(rec, &h, sizeof(h));
+        memcpy(rec + MVHP_MB_HEADER_BYTES, area, sizeof(area));
+        return RC_SUCCESS;
+    }
+    uint8_t *rec = cw_;   // compact record in its dense form (flags bit 0): header + the 768-byte area
+    mb_off_[addr] = (uint32_t)(rec - cw_base_);
+    h.flags = 1;
+    memcpy(rec, &h, sizeof(h));
+    memcpy(rec + MVHP_MB_HEADER_BYTES, area, sizeof(area));
+    cw_ = rec + MVHP_MB_HEADER_BYTES + sizeof(area);
+    return RC_SUCCESS;
+}
+
 // H7: macroblock_layer, h264_macroblock.c:75-313
 int PictureDecoder::macroblock(int addr, std::string &err)
 {
@@ -417,7 +620,10 @@ int PictureDecoder::macroblock(int addr, std::string &err)
         coef_ = reinterpret_cast<int16_t *>(out_ + (size_t)addr * MVHP_MB_BYTES + MVHP_MB_HEADER_BYTES);
     }
     const unsigned mb_type = cabac ? cabac_->mb_type(addr) : br_.ue();
-    if (mb_type == 25) { err = "I_PCM macroblocks are not supported"; return RC_UNSUPPORTED; } // :151-154
+    if (mb_type == 25) {   // I_PCM: the reference answers UNSUPPORTED (:151-154); by the standard (spec mode) 7.3.5 / 8.3.5
+        if (!spec_) { err = "I_PCM macroblocks are not supported"; return RC_UNSUPPORTED; }
+        return pcm_samples(addr, err);
+    }
     if (mb_type > 25) { err = "invalid mb_type in an I slice"; return RC_FAILURE; }
     mb.mb_type = (uint8_t)mb_type;
     uint8_t prev_flag[16] = {0}, rem[16] = {0};
@@ -485,6 +691,7 @@ int PictureDecoder::macroblock(int addr, std::string &err)
     h.cbp = (uint8_t)(mb.cbp_luma | (mb.cbp_chroma << 4));
     h.chroma_pred_mode = mb.chroma_pred_mode;
     h.i16_pred_mode = (uint8_t)i16_mode;
+    h.unavail = unavail_bits(addr);
     memcpy(h.pred_mode, mb.pred, 16);
     uint32_t nz = nz_cur_;   // collected while the blocks were decoded: every decoded level is non-zero
     if (mb.kind == MVHP_KIND_I8x8)

@@ -27,6 +27,19 @@ namespace h264 {
 
 enum { RC_UNSUPPORTED = -1, RC_FAILURE = 0, RC_SUCCESS = 1 }; // typedef.h:40-42
 
+// scaling_list() data of an SPS or a PPS (7.3.2.1.1.1), as transmitted: list i < 6 is 4x4 (Intra Y, Cb, Cr, Inter Y, Cb, Cr),
+// list 6 / 7 is 8x8 (Intra Y / Inter Y), each in zig-zag order.  state: 0 = not present (fall-back rule applies), 1 =
+// transmitted, 2 = transmitted as "use the default list" (useDefaultScalingMatrixFlag).
+struct ScalingLists {
+    bool    present = false;            // seq_ / pic_scaling_matrix_present_flag
+    uint8_t state[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint8_t l4[6][16] = {{0}};
+    uint8_t l8[2][64] = {{0}};
+};
+// The weight matrices an Intra picture uses (Intra Y / Cb / Cr 4x4 and Intra Y 8x8), in RASTER order, after the fall-back
+// rules of 7.4.2.1.1 (set A, SPS) and 7.4.2.2 (set A or B, PPS).  Returns true when any weight differs from 16.
+bool effective_intra_scaling(const ScalingLists &sps, const ScalingLists &pps, bool transform8x8, uint8_t w4[3][16], uint8_t w8[64]);
+
 struct Sps {
     bool     valid = false;
     int      profile_idc = 0, level_idc = 0, sps_id = 0;
@@ -40,6 +53,7 @@ struct Sps {
     bool     frame_cropping = false;
     int      crop[4] = {0, 0, 0, 0};
     bool     qpprime_y_zero_transform_bypass = false;
+    ScalingLists scaling;   // seq_scaling_matrix (only parsed for MVHP_STREAM_SPEC streams; the reference envelope has none)
 };
 
 struct Pps {
@@ -56,6 +70,7 @@ struct Pps {
     bool constrained_intra_pred = false;
     bool redundant_pic_cnt_present = false;
     bool transform_8x8_mode = false;
+    ScalingLists scaling;   // pic_scaling_matrix (MVHP_STREAM_SPEC streams only)
 };
 
 // One entry of the elementary-stream sample table (bitstream_map_struct.h:46-129,
@@ -75,13 +90,14 @@ int  index_annexb(const uint8_t *data, size_t size, std::vector<EsSample> &out);
 // Annex B as the standard defines it (MVHP_STREAM_SPEC): 3- or 4-byte start codes, any nal_ref_idc, scan to the end
 int  index_annexb_spec(const uint8_t *data, size_t size, std::vector<EsSample> &out);
 void unescape_rbsp(const uint8_t *src, size_t n, std::vector<uint8_t> &dst);
-int  parse_sps(BitReader &br, Sps &sps, std::string &err);
-int  parse_pps(BitReader &br, const Sps *sps_table /*[32]*/, Pps &pps, std::string &err);
+// `spec` (MVHP_STREAM_SPEC): scaling lists are parsed (7.3.2.1.1.1) instead of refused
+int  parse_sps(BitReader &br, Sps &sps, std::string &err, bool spec = false);
+int  parse_pps(BitReader &br, const Sps *sps_table /*[32]*/, Pps &pps, std::string &err, bool spec = false);
 
 // Per-macroblock state kept for neighbour derivations (nC, ctxIdxInc, pred modes).
 struct MbState {
     uint8_t  kind = 0;          // MVHP_KIND_*
-    uint8_t  mb_type = 0;       // raw I-slice mb_type 0..24
+    uint8_t  mb_type = 0;       // raw I-slice mb_type 0..25
     uint8_t  cbp_luma = 0, cbp_chroma = 0;
     uint8_t  chroma_pred_mode = 0;
     uint8_t  qp_delta_nonzero = 0;
@@ -94,15 +110,27 @@ struct MbState {
 
 struct CabacEngine;
 
+// one slice NAL of a picture: payload after the NAL header byte, emulation prevention removed
+struct SliceRbsp {
+    const uint8_t *rbsp = nullptr;
+    size_t         n = 0;
+    int            nal_ref_idc = 0;
+};
+
 class PictureDecoder {
 public:
-    PictureDecoder(const Sps &sps, const Pps &pps, int nal_ref_idc);
+    // spec = MVHP_STREAM_SPEC: the standard's slice semantics (first_mb_in_slice honoured, a slice ends where its data ends,
+    // I_PCM accepted); otherwise the reference's (one slice NAL = one picture decoded from macroblock 0, h264_slice.c:1019)
+    PictureDecoder(const Sps &sps, const Pps &pps, int nal_ref_idc, bool spec = false);
     ~PictureDecoder();
     // rbsp: slice NAL payload (after the NAL header byte), emulation prevention removed.
     int decode(const uint8_t *rbsp, size_t n, uint8_t *packed, size_t packed_bytes, std::string &err);
     // The same picture in the COMPACT transfer format (include/minivideo_hotpath.h, "compact pictures"): the levels that
     // are zero -- most of an 800-byte record -- never cross the PCIe link; the GPU expands it into packed records.
     int decode_compact(const uint8_t *rbsp, size_t n, uint8_t *buf, size_t cap, size_t *used, std::string &err);
+    // A picture of several slices (spec mode): the slices in macroblock order, together covering the picture.
+    int decode_slices(const SliceRbsp *slices, int n_slices, uint8_t *packed, size_t packed_bytes, std::string &err);
+    int decode_slices_compact(const SliceRbsp *slices, int n_slices, uint8_t *buf, size_t cap, size_t *used, std::string &err);
 
 private:
     friend struct CabacEngine;
@@ -135,9 +163,10 @@ private:
         nz_cur_ |= sink_.nz_per_coef ? (sink_.nz_bit << slot) : sink_.nz_bit;
     }
 
-    // neighbour helpers: address of MB A/B or -1 (cached for the macroblock being parsed: no division per call)
-    int mbA(int addr) const { return addr == cur_addr_ ? curA_ : ((addr % W_) > 0 ? addr - 1 : -1); }
-    int mbB(int addr) const { return addr >= W_ ? addr - W_ : -1; }
+    // neighbour helpers: address of MB A/B or -1 (cached for the macroblock being parsed: no division per call); a
+    // macroblock of an earlier slice is not available (6.4.8; slice_first_ = 0 for the reference's one-slice pictures)
+    int mbA(int addr) const { return addr == cur_addr_ ? curA_ : (((addr % W_) > 0 && addr - 1 >= slice_first_) ? addr - 1 : -1); }
+    int mbB(int addr) const { return addr - W_ >= slice_first_ ? addr - W_ : -1; }
 
     const Sps &sps_;
     const Pps &pps_;
@@ -156,7 +185,13 @@ private:
     uint32_t  *cwl_ = nullptr;
     uint32_t   compact_max_ = MVHP_COMPACT_MAX_ENTRIES;
     uint32_t  *mb_off_ = nullptr;
-    int  run(std::string &err);
+    int  run(const SliceRbsp *slices, int n_slices, std::string &err);
+    int  pcm_samples(int addr, std::string &err);
+    uint8_t unavail_bits(int addr) const;
+    bool       spec_ = false;
+    int        slice_first_ = 0;     // address of the first macroblock of the slice being parsed
+    int        next_addr_ = 0;       // macroblocks decoded so far (= the address the next slice must start at)
+    bool       multi_slice_ = false; // records carry MVHP_UNAVAIL_* bits
     int        cur_addr_ = -1, curA_ = -1, cur_x_ = 0;   // the macroblock being parsed, its left neighbour, its column
     uint32_t   nz_cur_ = 0;      // nz_mask of the macroblock being decoded
 };

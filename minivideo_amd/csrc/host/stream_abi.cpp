@@ -34,11 +34,11 @@ int mvhp_stream::build(std::string &err)
         std::string e;
         if (s.nal_unit_type == 7) {
             Sps sps;
-            if (parse_sps(br, sps, e) == RC_SUCCESS) sps_tab[sps.sps_id] = sps;
+            if (parse_sps(br, sps, e, spec) == RC_SUCCESS) sps_tab[sps.sps_id] = sps;
             else param_errors++;
         } else if (s.nal_unit_type == 8) {
             Pps pps;
-            if (parse_pps(br, sps_tab, pps, e) == RC_SUCCESS) pps_tab[pps.pps_id] = pps;
+            if (parse_pps(br, sps_tab, pps, e, spec) == RC_SUCCESS) pps_tab[pps.pps_id] = pps;
             else param_errors++;
         } else if (s.nal_unit_type == 5) {
             Idr idr;
@@ -52,9 +52,10 @@ int mvhp_stream::build(std::string &err)
                 idr.ok = slice_can_hold_picture(idr.sps, s.nal_size);
                 if (!idr.ok) idr.why = "slice NAL too small for the picture size of its SPS";
                 if (spec && first_mb != 0) {   // a further slice of the previous picture: not a picture of its own
-                    idr.ok = false;
-                    idr.why = "pictures of several slices are not supported (one slice per picture)";
-                    if (!idrs.empty() && idrs.back().ok) { idrs.back().ok = false; idrs.back().why = idr.why; }
+                    if (idrs.empty()) continue;                       // (a stream that starts in the middle of a picture)
+                    Idr &pic = idrs.back();
+                    if (pic.ok && pic.pps.pps_id != (int)pid) { pic.ok = false; pic.why = "the slices of a picture refer to different picture parameter sets"; }
+                    pic.more.push_back(i);
                     continue;
                 }
             } else {
@@ -132,16 +133,31 @@ int mvhp_stream::build_mp4(std::string &err)
     return RC_SUCCESS;
 }
 
+// the slice NAL units of picture `idr`, unescaped: one in the reference's world, several for MVHP_STREAM_SPEC streams
+static void picture_slices(const mvhp_stream &st, const mvhp_stream::Idr &idr, std::vector<std::vector<uint8_t>> &store,
+                           std::vector<SliceRbsp> &slices)
+{
+    store.resize(1 + idr.more.size());
+    slices.resize(store.size());
+    for (size_t k = 0; k < store.size(); k++) {
+        const EsSample &s = st.samples[k == 0 ? idr.sample : idr.more[k - 1]];
+        unescape_rbsp(st.data + s.offset + 1, s.nal_size - 1, store[k]);
+        slices[k].rbsp = store[k].data();
+        slices[k].n = store[k].size();
+        slices[k].nal_ref_idc = s.nal_ref_idc;
+    }
+}
+
 int mvhp_stream::decode_packed(int k, void *packed, size_t bytes, std::string &err) const
 {
     if (k < 0 || (size_t)k >= idrs.size()) { err = "IDR index out of range"; return RC_FAILURE; }
     const Idr &idr = idrs[k];
     if (!idr.ok) { err = idr.why; return RC_FAILURE; }
-    const EsSample &s = samples[idr.sample];
-    std::vector<uint8_t> rbsp;
-    unescape_rbsp(data + s.offset + 1, s.nal_size - 1, rbsp);
-    PictureDecoder pd(idr.sps, idr.pps, s.nal_ref_idc);
-    return pd.decode(rbsp.data(), rbsp.size(), (uint8_t *)packed, bytes, err);
+    std::vector<std::vector<uint8_t>> store;
+    std::vector<SliceRbsp> slices;
+    picture_slices(*this, idr, store, slices);
+    PictureDecoder pd(idr.sps, idr.pps, slices[0].nal_ref_idc, spec);
+    return pd.decode_slices(slices.data(), (int)slices.size(), (uint8_t *)packed, bytes, err);
 }
 
 int mvhp_stream::decode_compact(int k, void *buf, size_t cap, size_t *used, std::string &err) const
@@ -150,11 +166,11 @@ int mvhp_stream::decode_compact(int k, void *buf, size_t cap, size_t *used, std:
     if (k < 0 || (size_t)k >= idrs.size()) { err = "IDR index out of range"; return RC_FAILURE; }
     const Idr &idr = idrs[k];
     if (!idr.ok) { err = idr.why; return RC_FAILURE; }
-    const EsSample &s = samples[idr.sample];
-    std::vector<uint8_t> rbsp;
-    unescape_rbsp(data + s.offset + 1, s.nal_size - 1, rbsp);
-    PictureDecoder pd(idr.sps, idr.pps, s.nal_ref_idc);
-    return pd.decode_compact(rbsp.data(), rbsp.size(), (uint8_t *)buf, cap, used, err);
+    std::vector<std::vector<uint8_t>> store;
+    std::vector<SliceRbsp> slices;
+    picture_slices(*this, idr, store, slices);
+    PictureDecoder pd(idr.sps, idr.pps, slices[0].nal_ref_idc, spec);
+    return pd.decode_slices_compact(slices.data(), (int)slices.size(), (uint8_t *)buf, cap, used, err);
 }
 
 static thread_local std::string g_stream_err;
@@ -213,6 +229,14 @@ MVHP_EXPORT int mvhp_stream_params(const mvhp_stream_t *s, int idr, mvhp_stream_
     out->chroma_qp_index_offset = i.pps.chroma_qp_index_offset;
     out->second_chroma_qp_index_offset = i.pps.second_chroma_qp_index_offset;
     out->flags = (i.pps.transform_8x8_mode ? MVHP_PARAM_MAY_HAVE_8X8 : 0u) | (s->spec ? MVHP_PARAM_SPEC_LUMA_DC : 0u);
+    memset(out->scaling4, 16, sizeof(out->scaling4));
+    memset(out->scaling8, 16, sizeof(out->scaling8));
+    if (s->spec) {   // SURVEY 8f row f4 (outside parity): several slices, scaling matrices
+        if (!i.more.empty()) out->flags |= MVHP_PARAM_SLICES;
+        if ((i.sps.scaling.present || i.pps.scaling.present) &&
+            effective_intra_scaling(i.sps.scaling, i.pps.scaling, i.pps.transform_8x8_mode, out->scaling4, out->scaling8))
+            out->flags |= MVHP_PARAM_SCALING;
+    }
     return MVHP_SUCCESS;
 }
 

@@ -8,6 +8,7 @@
 struct mvhp_stream {
     struct Idr {
         size_t      sample = 0;   // index into samples
+        std::vector<size_t> more; // MVHP_STREAM_SPEC: the further slice NAL units of the picture (first_mb_in_slice > 0)
         h264::Sps   sps;          // parameter sets in force when this picture was reached
         h264::Pps   pps;
         bool        ok = false;

@@ -24,6 +24,8 @@ class StreamParams(C.Structure):
         ("chroma_qp_index_offset", C.c_int32),
         ("second_chroma_qp_index_offset", C.c_int32),
         ("flags", C.c_uint32),
+        ("scaling4", (C.c_uint8 * 16) * 3),   # MVHP_PARAM_SCALING: weight matrices, raster order (Intra Y, Cb, Cr)
+        ("scaling8", C.c_uint8 * 64),         # ... Intra Y 8x8
     ]
 
     @property

@@ -48,16 +48,19 @@ static const int v8x8[6][6] = {
     {20, 18, 32, 19, 25, 24}, {22, 19, 35, 21, 28, 26}, {26, 23, 42, 24, 33, 31},
     {28, 25, 45, 26, 35, 33}, {32, 28, 51, 30, 40, 38}, {36, 32, 58, 34, 46, 43}};
 
-static int level_scale4(int q, int i, int j)
+/* LevelScale = weightScale * normAdjust (h264_transform.c:645-741).  `w` is the weight matrix in raster order: all 16
+ * (Flat_4x4_16 / Flat_8x8_16) inside the reference's envelope; a stream's SPS / PPS scaling lists only for streams opened
+ * with MVHP_STREAM_SPEC (MVHP_PARAM_SCALING, outside parity: 8.5.9 of the standard is the authority there). */
+static int level_scale4(const uint8_t *w, int q, int i, int j)
 {
     int k;
     if ((i % 2 == 0) && (j % 2 == 0)) k = 0;
     else if ((i % 2 == 1) && (j % 2 == 1)) k = 1;
     else k = 2;
-    return 16 * v4x4[q][k];
+    return w[i * 4 + j] * v4x4[q][k];
 }
 
-static int level_scale8(int q, int i, int j)
+static int level_scale8(const uint8_t *w, int q, int i, int j)
 {
     int k;
     if ((i % 4 == 0) && (j % 4 == 0)) k = 0;
@@ -66,7 +69,7 @@ static int level_scale8(int q, int i, int j)
     else if (((i % 4 == 0) && (j % 2 == 1)) || ((i % 2 == 1) && (j % 4 == 0))) k = 3;
     else if (((i % 4 == 0) && (j % 4 == 2)) || ((i % 4 == 2) && (j % 4 == 0))) k = 4;
     else k = 5;
-    return 16 * v8x8[q][k];
+    return w[i * 8 + j] * v8x8[q][k];
 }
 
 /* Table 8-15, h264_transform.c:71 */
@@ -98,6 +101,8 @@ typedef struct {
     int cqp_off[2];
     int dc_shift_from;        /* 37 = reference (`qP > 36`), 36 = standard (MVHP_PARAM_SPEC_LUMA_DC) */
     int mbx, mby;             /* current macroblock */
+    unsigned unavail;         /* MVHP_UNAVAIL_* of the current macroblock: neighbours in another slice (MVHP_PARAM_SLICES) */
+    uint8_t w4[3][16], w8[64];/* weight matrices, raster order (flat 16 unless MVHP_PARAM_SCALING) */
 } pic_t;
 
 /* deriv_neighbouringlocations (h264_spatial.c:739-786) + availability by
@@ -108,11 +113,11 @@ static int neigh_sample(const pic_t *p, const uint8_t *plane, int pitch, int max
 {
     int mx = p->mbx, my = p->mby;
     if (yN > maxW - 1) return 0;
-    if (xN < 0 && yN < 0) { mx -= 1; my -= 1; }                 /* D */
-    else if (xN < 0) { mx -= 1; }                               /* A */
-    else if (xN <= maxW - 1 && yN < 0) { my -= 1; }             /* B */
+    if (xN < 0 && yN < 0) { mx -= 1; my -= 1; if (p->unavail & MVHP_UNAVAIL_D) return 0; }  /* D */
+    else if (xN < 0) { mx -= 1; if (p->unavail & MVHP_UNAVAIL_A) return 0; }                /* A */
+    else if (xN <= maxW - 1 && yN < 0) { my -= 1; if (p->unavail & MVHP_UNAVAIL_B) return 0; } /* B */
     else if (xN <= maxW - 1) { /* current macroblock */ }
-    else if (yN < 0) { mx += 1; my -= 1; }                      /* C */
+    else if (yN < 0) { mx += 1; my -= 1; if (p->unavail & MVHP_UNAVAIL_C) return 0; }       /* C */
     else return 0;                                              /* right of MB: not available */
     if (mx < 0 || my < 0 || mx >= p->W) return 0;
     {
@@ -159,37 +164,37 @@ static void idct4x4(const int d[4][4], int r[4][4])
 
 /* quant4x4 + idct4x4 = transform_4x4_residual, h264_transform.c:1049-1134.
  * keep_dc: Intra_16x16 luma or any chroma block (d[0][0] = c[0][0], :1126). */
-static void residual4x4(const int c[4][4], int qP, int keep_dc, int r[4][4])
+static void residual4x4(const uint8_t *w, const int c[4][4], int qP, int keep_dc, int r[4][4])
 {
     int d[4][4], i, j, m = qP % 6, s = qP / 6;
     if (qP > 23) {
         for (i = 0; i < 4; i++)
             for (j = 0; j < 4; j++)
-                d[i][j] = wshl(c[i][j] * level_scale4(m, i, j), s - 4);
+                d[i][j] = wshl(c[i][j] * level_scale4(w, m, i, j), s - 4);
     } else {
         int rnd = 1 << (3 - s);
         for (i = 0; i < 4; i++)
             for (j = 0; j < 4; j++)
-                d[i][j] = (c[i][j] * level_scale4(m, i, j) + rnd) >> (4 - s);
+                d[i][j] = (c[i][j] * level_scale4(w, m, i, j) + rnd) >> (4 - s);
     }
     if (keep_dc) d[0][0] = c[0][0];
     idct4x4(d, r);
 }
 
 /* quant8x8 + idct8x8 = transform_8x8_residual, h264_transform.c:1205-1383 */
-static void residual8x8(const int c[8][8], int qP, int r[8][8])
+static void residual8x8(const uint8_t *w, const int c[8][8], int qP, int r[8][8])
 {
     int d[8][8], e[8][8], f[8][8], g[8][8], h[8][8], k[8][8], mm[8][8];
     int i, j, m = qP % 6, s = qP / 6;
     if (qP > 35) {
         for (i = 0; i < 8; i++)
             for (j = 0; j < 8; j++)
-                d[i][j] = wshl(c[i][j] * level_scale8(m, i, j), s - 6);
+                d[i][j] = wshl(c[i][j] * level_scale8(w, m, i, j), s - 6);
     } else {
         int rnd = 1 << (5 - s);
         for (i = 0; i < 8; i++)
             for (j = 0; j < 8; j++)
-                d[i][j] = (c[i][j] * level_scale8(m, i, j) + rnd) >> (6 - s);
+                d[i][j] = (c[i][j] * level_scale8(w, m, i, j) + rnd) >> (6 - s);
     }
     for (i = 0; i < 8; i++) {
         e[i][0] = d[i][0] + d[i][4];
@@ -259,11 +264,11 @@ static void residual8x8(const int c[8][8], int qP, int r[8][8])
 /* transform_16x16_lumadc, h264_transform.c:756-812 -- including the
  * `qP > 36` test (the standard says >= 36): at QP'Y == 36 the reference
  * evaluates (f*LS + (1 << -1)) >> 0. */
-static void luma_dc(const int c[4][4], int qP, int shift_from, int dcY[4][4])
+static void luma_dc(const uint8_t *w, const int c[4][4], int qP, int shift_from, int dcY[4][4])
 {
     static const int H4[4][4] = {{1, 1, 1, 1}, {1, 1, -1, -1}, {1, -1, -1, 1}, {1, -1, 1, -1}};
     int f1[4][4] = {{0}}, f2[4][4] = {{0}}, i, j, k;
-    int m = qP % 6, s = qP / 6, ls = level_scale4(m, 0, 0);
+    int m = qP % 6, s = qP / 6, ls = level_scale4(w, m, 0, 0);
     for (i = 0; i < 4; i++)
         for (j = 0; j < 4; j++)
             for (k = 0; k < 4; k++)
@@ -284,9 +289,9 @@ static void luma_dc(const int c[4][4], int qP, int shift_from, int dcY[4][4])
 }
 
 /* transform_2x2_chromadc, h264_transform.c:827-860, 924-936, 988-1005 */
-static void chroma_dc(const int c[4], int qPc, int dcC[4])
+static void chroma_dc(const uint8_t *w, const int c[4], int qPc, int dcC[4])
 {
-    int f[4], ls = level_scale4(qPc % 6, 0, 0), k;
+    int f[4], ls = level_scale4(w, qPc % 6, 0, 0), k;
     f[0] = c[0] + c[1] + c[2] + c[3];
     f[1] = c[0] - c[1] + c[2] - c[3];
     f[2] = c[0] + c[1] - c[2] - c[3];
@@ -542,7 +547,7 @@ static void recon_i4x4(pic_t *p, const mvhp_mb_header_t *h, const int16_t *coef)
         fetch_edges(p, xO, yO, 4, blk, &ip);
         pred4x4(&ip, h->pred_mode[blk], pred);
         load_c4(coef + blk * 16, c);
-        residual4x4(c, h->qp_y, 0, r);
+        residual4x4(p->w4[0], c, h->qp_y, 0, r);
         for (y = 0; y < 4; y++)
             for (x = 0; x < 4; x++)
                 p->y[(size_t)(p->mby * 16 + yO + y) * p->pitch + p->mbx * 16 + xO + x] =
@@ -562,7 +567,7 @@ static void recon_i8x8(pic_t *p, const mvhp_mb_header_t *h, const int16_t *coef)
         filter8x8(&ip, &f);
         pred8x8(&f, h->pred_mode[blk], pred);
         for (i = 0; i < 8; i++) for (j = 0; j < 8; j++) c[i][j] = coef[blk * 64 + i * 8 + j];
-        residual8x8(c, h->qp_y, r);
+        residual8x8(p->w8, c, h->qp_y, r);
         for (y = 0; y < 8; y++)
             for (x = 0; x < 8; x++)
                 p->y[(size_t)(p->mby * 16 + yO + y) * p->pitch + p->mbx * 16 + xO + x] =
@@ -621,13 +626,13 @@ static void recon_i16x16(pic_t *p, const mvhp_mb_header_t *h, const int16_t *coe
         blk4_xy(blk, &xO, &yO);
         c1[yO / 4][xO / 4] = coef[blk * 16];
     }
-    luma_dc(c1, h->qp_y, p->dc_shift_from, dcY);
+    luma_dc(p->w4[0], c1, h->qp_y, p->dc_shift_from, dcY);
     for (blk = 0; blk < 16; blk++) {
         int xO, yO, c[4][4], r[4][4];
         blk4_xy(blk, &xO, &yO);
         load_c4(coef + blk * 16, c);
         c[0][0] = dcY[yO / 4][xO / 4];
-        residual4x4(c, h->qp_y, 1, r);
+        residual4x4(p->w4[0], c, h->qp_y, 1, r);
         for (y = 0; y < 4; y++) for (x = 0; x < 4; x++) rMb[xO + x][yO + y] = r[y][x];
     }
     for (y = 0; y < 16; y++)
@@ -691,12 +696,12 @@ static void recon_chroma(pic_t *p, const mvhp_mb_header_t *h, const int16_t *coe
         break;
     }
     for (blk = 0; blk < 4; blk++) cdc[blk] = coef[blk * 16];
-    chroma_dc(cdc, qPc, dcC);
+    chroma_dc(p->w4[1 + iCbCr], cdc, qPc, dcC);
     for (blk = 0; blk < 4; blk++) {
         int xO = (blk % 2) * 4, yO = (blk / 2) * 4, c[4][4], r[4][4];
         load_c4(coef + blk * 16, c);
         c[0][0] = dcC[blk];
-        residual4x4(c, qPc, 1, r);
+        residual4x4(p->w4[1 + iCbCr], c, qPc, 1, r);
         for (y = 0; y < 4; y++) for (x = 0; x < 4; x++) rMb[xO + x][yO + y] = r[y][x];
     }
     for (y = 0; y < 8; y++)
@@ -718,12 +723,35 @@ ORC_EXPORT int orc_recon_frame(const mvhp_stream_params_t *sp, const void *packe
     p.cqp_off[0] = sp->chroma_qp_index_offset;
     p.cqp_off[1] = sp->second_chroma_qp_index_offset;
     p.dc_shift_from = (sp->flags & MVHP_PARAM_SPEC_LUMA_DC) ? 36 : 37;
+    if (sp->flags & MVHP_PARAM_SCALING) {
+        memcpy(p.w4, sp->scaling4, sizeof(p.w4));
+        memcpy(p.w8, sp->scaling8, sizeof(p.w8));
+    } else {
+        memset(p.w4, 16, sizeof(p.w4));
+        memset(p.w8, 16, sizeof(p.w8));
+    }
     for (mb = 0; mb < W * H; mb++) {
         mvhp_mb_header_t h;
         int16_t coef[MVHP_MB_COEFS];
         memcpy(&h, base + (size_t)mb * MVHP_MB_BYTES, sizeof(h));
         memcpy(coef, base + (size_t)mb * MVHP_MB_BYTES + MVHP_MB_HEADER_BYTES, sizeof(coef));
         p.mbx = mb % W; p.mby = mb / W;
+        p.unavail = (sp->flags & MVHP_PARAM_SLICES) ? h.unavail : 0u;
+        if (h.mb_kind == MVHP_KIND_IPCM) {   /* I_PCM (8.3.5): the samples as they are; layout in minivideo_hotpath.h */
+            const uint8_t *smp = base + (size_t)mb * MVHP_MB_BYTES + MVHP_MB_HEADER_BYTES;
+            int j, x;
+            for (j = 0; j < 8; j++) {
+                for (x = 0; x < 16; x++) {
+                    p.y[(size_t)(p.mby * 16 + 2 * j) * p.pitch + p.mbx * 16 + x] = smp[64 * j + x];
+                    p.y[(size_t)(p.mby * 16 + 2 * j + 1) * p.pitch + p.mbx * 16 + x] = smp[64 * j + 16 + x];
+                }
+                for (x = 0; x < 8; x++) {
+                    p.cb[(size_t)(p.mby * 8 + j) * p.cpitch + p.mbx * 8 + x] = smp[64 * j + 32 + x];
+                    p.cr[(size_t)(p.mby * 8 + j) * p.cpitch + p.mbx * 8 + x] = smp[64 * j + 40 + x];
+                }
+            }
+            continue;
+        }
         if (h.mb_kind == MVHP_KIND_I4x4) recon_i4x4(&p, &h, coef);
         else if (h.mb_kind == MVHP_KIND_I8x8) recon_i8x8(&p, &h, coef);
         else if (h.mb_kind == MVHP_KIND_I16x16) recon_i16x16(&p, &h, coef);
