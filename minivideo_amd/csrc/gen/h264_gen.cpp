@@ -9,6 +9,9 @@
 // syntax elements with a formulation independent of the decoder's (picture-wide
 // 4x4-block maps instead of per-macroblock neighbour walks), so that
 // "generate -> parse -> compare records" is a genuine two-implementation check.
+// mvgen_stream_ex() additionally leaves the reference's envelope on request (what MVHP_STREAM_SPEC decodes
+// by the standard): several slices per picture, I_PCM macroblocks, SPS / PPS scaling lists (with the fall-back rules
+// evaluated here independently of the decoder's formulation).
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -132,6 +135,7 @@ struct CabacEnc {
         else if (low < 512) put(0);
         else { low -= 512; outstanding++; }
     }
+    void restart() { low = 0; range = 510; outstanding = 0; first = true; }   // 9.3.1.2 behind pcm samples: contexts kept
     void terminate(int bin)
     {
         range -= 2;
@@ -159,9 +163,18 @@ struct Maps {
     std::vector<uint8_t> cbfc[2];  // [H*2][W*2] chroma AC cbf
     // per macroblock
     std::vector<uint8_t> mbtype, cbp_l, cbp_c, cmode, t8, dqp_nz, cbf_dc, cbf_cdc[2], kind;
+    std::vector<int> slice;        // per macroblock: index of its slice; -1 = not written yet
+    int cur_slice = 0;
+    // 6.4.8: a macroblock is available to the one being written when it exists, precedes it and lies in the same slice
+    bool mb_avail(int mbx, int mby) const { return mbx >= 0 && mby >= 0 && mbx < W && slice[(size_t)mby * W + mbx] == cur_slice; }
+    // the same for the macroblock that holds 4x4 luma block (bx, by) / 4x4 chroma block (cx, cy), picture coordinates
+    bool blk_avail(int bx, int by) const { return bx >= 0 && by >= 0 && mb_avail(bx >> 2, by >> 2); }
+    bool cblk_avail(int cx, int cy) const { return cx >= 0 && cy >= 0 && mb_avail(cx >> 1, cy >> 1); }
     void init(int w, int h)
     {
         W = w; H = h;
+        slice.assign((size_t)W * H, -1);
+        cur_slice = 0;
         mode4.assign((size_t)W * H * 16, -1);
         tc.assign((size_t)W * H * 16, 0);
         cbf.assign((size_t)W * H * 16, 0);
@@ -185,9 +198,15 @@ struct GenCfg {
     int allow_qp36_i16;
     int qp_min, qp_max;   // slice QP range
     int max_level;        // |level| cap
+    // outside the reference's envelope (mvgen_stream_ex; all 0 = inside)
+    int n_slices = 1;     // slices per picture
+    int pcm_permille = 0; // share of I_PCM macroblocks
+    int scaling = 0;      // bit 0: scaling lists in the SPS, bit 1: in the PPS (profile 100 only)
 };
 
 struct MbSyntax {
+    int pcm;                   // I_PCM (mb_type 25): samples[] = 256 luma (raster), 64 Cb, 64 Cr
+    uint8_t samples[384];
     int mb_type;               // 0 I_NxN, 1..24 I16x16
     int t8;
     int pred[16];              // desired final modes (16 or 4)
@@ -236,7 +255,7 @@ struct Gen {
     // predIntraNxNPredMode for the block whose top-left 4x4 is (bx,by); n4 = 1 (4x4) or 2 (8x8)
     int predicted_mode(int bx, int by, int n4) const
     {
-        if (bx == 0 || by == 0) return 2; // a neighbour macroblock is unavailable -> DC
+        if (!m.blk_avail(bx - 1, by) || !m.blk_avail(bx, by - 1)) return 2; // a neighbour macroblock is unavailable -> DC
         int mA, mB;
         if (n4 == 1) { mA = pred_mode_of(bx - 1, by); mB = pred_mode_of(bx, by - 1); }
         else {
@@ -253,8 +272,21 @@ struct Gen {
     void draw_mb(int mbx, int mby, int qp_prev, MbSyntax &s)
     {
         memset(&s, 0, sizeof(s));
-        const bool A = mbx > 0, B = mby > 0, C = B && mbx < W - 1, D = A && B;
+        const bool A = m.mb_avail(mbx - 1, mby), B = m.mb_avail(mbx, mby - 1), C = m.mb_avail(mbx + 1, mby - 1),
+                   D = m.mb_avail(mbx - 1, mby - 1);
         (void)C;
+        if (cfg.pcm_permille > 0 && rng.below(1000) < cfg.pcm_permille) {
+            s.pcm = 1;
+            s.mb_type = 25;
+            const int base = rng.below(256), spread = 1 + rng.below(64);
+            for (int i = 0; i < 384; i++) {
+                int v = base + rng.below(2 * spread + 1) - spread;
+                if (rng.below(16) == 0) v = rng.below(2) ? 0 : 255;   // the extremes too (0x00 needs emulation prevention)
+                s.samples[i] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+            }
+            s.qp = qp_prev;   // no mb_qp_delta: QP'Y carries over (7.4.5)
+            return;
+        }
         const bool i16 = rng.uni() < (cfg.dense ? 0.4 : 0.5);
         if (!i16) {
             s.mb_type = 0;
@@ -351,9 +383,34 @@ struct Gen {
     }
 
     // ---- expected packed record (independent of the decoder) ----
-    void fill_record(const MbSyntax &s, uint8_t *rec)
+    uint8_t unavail_bits(int mbx, int mby) const
+    {
+        uint8_t u = 0;   // neighbours that geometry has but the slice structure takes away
+        if (mbx > 0 && !m.mb_avail(mbx - 1, mby)) u |= MVHP_UNAVAIL_A;
+        if (mby > 0 && !m.mb_avail(mbx, mby - 1)) u |= MVHP_UNAVAIL_B;
+        if (mby > 0 && mbx < W - 1 && !m.mb_avail(mbx + 1, mby - 1)) u |= MVHP_UNAVAIL_C;
+        if (mbx > 0 && mby > 0 && !m.mb_avail(mbx - 1, mby - 1)) u |= MVHP_UNAVAIL_D;
+        return u;
+    }
+
+    void fill_record(const MbSyntax &s, uint8_t *rec, int mbx, int mby)
     {
         memset(rec, 0, MVHP_MB_BYTES);
+        if (s.pcm) {
+            mvhp_mb_header_t h;
+            memset(&h, 0, sizeof(h));
+            h.mb_kind = MVHP_KIND_IPCM;
+            h.qp_y = (uint8_t)s.qp;
+            h.unavail = unavail_bits(mbx, mby);
+            memcpy(rec, &h, sizeof(h));
+            uint8_t *area = rec + MVHP_MB_HEADER_BYTES;
+            for (int y = 0; y < 16; y++) memcpy(area + 64 * (y >> 1) + 16 * (y & 1), s.samples + 16 * y, 16);
+            for (int y = 0; y < 8; y++) {
+                memcpy(area + 64 * y + 32, s.samples + 256 + 8 * y, 8);
+                memcpy(area + 64 * y + 40, s.samples + 320 + 8 * y, 8);
+            }
+            return;
+        }
         int16_t *coef = reinterpret_cast<int16_t *>(rec + MVHP_MB_HEADER_BYTES);
         const bool i16 = s.mb_type != 0;
         const int kind = i16 ? MVHP_KIND_I16x16 : (s.t8 ? MVHP_KIND_I8x8 : MVHP_KIND_I4x4);
@@ -393,6 +450,7 @@ struct Gen {
         h.cbp = (uint8_t)(s.cbp_l | (s.cbp_c << 4));
         h.chroma_pred_mode = (uint8_t)s.cmode;
         h.i16_pred_mode = (uint8_t)(i16 ? (s.mb_type - 1) % 4 : 0);
+        h.unavail = unavail_bits(mbx, mby);
         if (!i16) for (int b = 0; b < (s.t8 ? 4 : 16); b++) h.pred_mode[b] = (uint8_t)s.pred[b];
         uint32_t nz = 0;
         for (int b = 0; b < 24; b++) {
@@ -466,23 +524,50 @@ struct Gen {
 
     int nC_luma(int bx, int by) const
     {
-        const bool a = bx > 0, b = by > 0;
+        const bool a = m.blk_avail(bx - 1, by), b = m.blk_avail(bx, by - 1);
         const int nA = a ? m.tc[(size_t)by * W * 4 + bx - 1] : 0, nB = b ? m.tc[(size_t)(by - 1) * W * 4 + bx] : 0;
         if (a && b) return (nA + nB + 1) >> 1;
         return a ? nA : (b ? nB : 0);
     }
     int nC_chroma(int c, int bx, int by) const
     {
-        const bool a = bx > 0, b = by > 0;
+        const bool a = m.cblk_avail(bx - 1, by), b = m.cblk_avail(bx, by - 1);
         const int nA = a ? m.tcc[c][(size_t)by * W * 2 + bx - 1] : 0, nB = b ? m.tcc[c][(size_t)(by - 1) * W * 2 + bx] : 0;
         if (a && b) return (nA + nB + 1) >> 1;
         return a ? nA : (b ? nB : 0);
+    }
+
+    // what later macroblocks derive from an I_PCM macroblock: nC = 16 (9.2.1), coded_block_flag = 1 (9.3.3.1.1.9), mb_type !=
+    // I_NxN, CodedBlockPattern 47 (9.3.3.1.1.4), intra_chroma_pred_mode 0, no transform_size_8x8_flag, mb_qp_delta 0
+    void publish_pcm(int mbx, int mby)
+    {
+        const int addr = mby * W + mbx;
+        for (int y = 0; y < 4; y++)
+            for (int x = 0; x < 4; x++) {
+                m.tc[(size_t)(mby * 4 + y) * W * 4 + mbx * 4 + x] = 16;
+                m.cbf[(size_t)(mby * 4 + y) * W * 4 + mbx * 4 + x] = 1;
+                m.mode4[(size_t)(mby * 4 + y) * W * 4 + mbx * 4 + x] = -1;
+            }
+        for (int c = 0; c < 2; c++)
+            for (int y = 0; y < 2; y++)
+                for (int x = 0; x < 2; x++) {
+                    m.tcc[c][(size_t)(mby * 2 + y) * W * 2 + mbx * 2 + x] = 16;
+                    m.cbfc[c][(size_t)(mby * 2 + y) * W * 2 + mbx * 2 + x] = 1;
+                }
+        m.mbtype[addr] = 25; m.cbp_l[addr] = 15; m.cbp_c[addr] = 2; m.cmode[addr] = 0; m.t8[addr] = 0;
+        m.kind[addr] = 3; m.dqp_nz[addr] = 0; m.cbf_dc[addr] = 1; m.cbf_cdc[0][addr] = 1; m.cbf_cdc[1][addr] = 1;
+    }
+    static void write_pcm_samples(BitWriter &bw, const MbSyntax &s)
+    {
+        while (!bw.aligned()) bw.bit(0);   // pcm_alignment_zero_bit
+        for (int i = 0; i < 384; i++) bw.bits(s.samples[i], 8);
     }
 
     void write_mb_cavlc(BitWriter &bw, int mbx, int mby, const MbSyntax &s)
     {
         const bool i16 = s.mb_type != 0;
         bw.ue((uint32_t)s.mb_type);
+        if (s.pcm) { write_pcm_samples(bw, s); publish_pcm(mbx, mby); return; }
         if (!i16) {
             if (cfg.transform8x8) bw.bit(s.t8);
             for (int b = 0; b < (s.t8 ? 4 : 16); b++) { bw.bit(s.prev_flag[b]); if (!s.prev_flag[b]) bw.bits((uint32_t)s.rem[b], 3); }
@@ -568,8 +653,17 @@ struct Gen {
 
     void write_mb_cabac(CabacEnc &e, int mbx, int mby, const MbSyntax &s)
     {
-        const int addr = mby * W + mbx, a = mbx > 0 ? addr - 1 : -1, b = mby > 0 ? addr - W : -1;
+        const int addr = mby * W + mbx, a = m.mb_avail(mbx - 1, mby) ? addr - 1 : -1, b = m.mb_avail(mbx, mby - 1) ? addr - W : -1;
         const bool i16 = s.mb_type != 0;
+        if (s.pcm) {   // mb_type I_PCM: prefix bin, terminate bin 1 (= EncodeFlush), alignment, samples, encoder restarted
+            const int inc = ((a >= 0 && m.mbtype[a] != 0) ? 1 : 0) + ((b >= 0 && m.mbtype[b] != 0) ? 1 : 0);
+            e.decision(3 + inc, 1);
+            e.terminate(1);
+            write_pcm_samples(e.bw, s);
+            e.restart();
+            publish_pcm(mbx, mby);
+            return;
+        }
         { // mb_type
             const int inc = ((a >= 0 && m.mbtype[a] != 0) ? 1 : 0) + ((b >= 0 && m.mbtype[b] != 0) ? 1 : 0);
             if (!i16) e.decision(3 + inc, 0);
@@ -621,7 +715,7 @@ struct Gen {
         if (!(i16 || s.cbp_l || s.cbp_c)) return;
         { // mb_qp_delta
             int inc = 0;
-            if (addr > 0) {
+            if (addr > 0 && m.slice[(size_t)addr - 1] == m.cur_slice) {   // the previous macroblock in decoding order of this slice
                 const int p = addr - 1;
                 const bool nores = (m.kind[p] != 2) && m.cbp_l[p] == 0 && m.cbp_c[p] == 0;
                 inc = (!nores && m.dqp_nz[p]) ? 1 : 0;
@@ -641,13 +735,13 @@ struct Gen {
         }
         // coded_block_flag ctxIdxInc from picture-wide maps: unavailable -> 1 (intra), uncoded 8x8 region -> 0
         auto luma_inc = [&](int bx, int by) {
-            const int cA = bx > 0 ? m.cbf[(size_t)by * W * 4 + bx - 1] : 1;
-            const int cB = by > 0 ? m.cbf[(size_t)(by - 1) * W * 4 + bx] : 1;
+            const int cA = m.blk_avail(bx - 1, by) ? m.cbf[(size_t)by * W * 4 + bx - 1] : 1;
+            const int cB = m.blk_avail(bx, by - 1) ? m.cbf[(size_t)(by - 1) * W * 4 + bx] : 1;
             return cA + 2 * cB;
         };
         if (i16) {
-            const int cA = a >= 0 ? (m.kind[a] == 2 ? m.cbf_dc[a] : 0) : 1;
-            const int cB = b >= 0 ? (m.kind[b] == 2 ? m.cbf_dc[b] : 0) : 1;
+            const int cA = a >= 0 ? (m.kind[a] >= 2 ? m.cbf_dc[a] : 0) : 1;   // (kind 3 = I_PCM: always 1)
+            const int cB = b >= 0 ? (m.kind[b] >= 2 ? m.cbf_dc[b] : 0) : 1;
             int f = 0;
             cabac_residual(e, s.dc16, 16, 2, cA + 2 * cB, &f);
             m.cbf_dc[addr] = (uint8_t)f;
@@ -682,13 +776,101 @@ struct Gen {
             for (int c = 0; c < 2; c++)
                 for (int blk = 0; blk < 4; blk++) {
                     const int bx = mbx * 2 + (blk & 1), by = mby * 2 + (blk >> 1);
-                    const int cA = bx > 0 ? m.cbfc[c][(size_t)by * W * 2 + bx - 1] : 1;
-                    const int cB = by > 0 ? m.cbfc[c][(size_t)(by - 1) * W * 2 + bx] : 1;
+                    const int cA = m.cblk_avail(bx - 1, by) ? m.cbfc[c][(size_t)by * W * 2 + bx - 1] : 1;
+                    const int cB = m.cblk_avail(bx, by - 1) ? m.cbfc[c][(size_t)(by - 1) * W * 2 + bx] : 1;
                     int f = 0;
                     cabac_residual(e, s.cac[c][blk], 15, 6 + c, cA + 2 * cB, &f);
                     m.cbfc[c][(size_t)by * W * 2 + bx] = (uint8_t)f;
                 }
         }
+    }
+
+    // ---- scaling lists (7.3.2.1.1.1; SPS and PPS of profile 100) ----
+    // A level's eight lists as drawn: state 0 = not transmitted, 1 = transmitted, 2 = transmitted as "use the default".
+    struct ListSet {
+        int present = 0;
+        int state[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        uint8_t v[8][64];
+    };
+    ListSet sps_lists, pps_lists;
+    void draw_lists(ListSet &ls, int n_lists)
+    {
+        ls.present = 1;
+        for (int i = 0; i < 8; i++) {
+            ls.state[i] = 0;
+            if (i >= n_lists) continue;
+            const int n = i < 6 ? 16 : 64, r = rng.below(10);
+            ls.state[i] = r < 3 ? 0 : (r < 5 ? 2 : 1);
+            if (ls.state[i] != 1) continue;
+            // a smooth ramp with noise, like real matrices, inside 1..255; now and then the list ends early (the rest repeats)
+            int cur = 4 + rng.below(28);
+            const int stop = rng.below(4) == 0 ? 1 + rng.below(n - 1) : n;
+            for (int j = 0; j < n; j++) {
+                if (j < stop) { cur += rng.below(7) - 2; cur = cur < 1 ? 1 : (cur > 255 ? 255 : cur); }
+                ls.v[i][j] = (uint8_t)cur;
+            }
+            if (rng.below(8) == 0) ls.v[i][rng.below(n)] = (uint8_t)(200 + rng.below(56));   // a large weight somewhere
+            if (stop < n) for (int j = stop; j < n; j++) ls.v[i][j] = ls.v[i][stop - 1];
+        }
+    }
+    static void write_list(BitWriter &bw, const uint8_t *v, int n, bool use_default)
+    {
+        if (use_default) { bw.se(-8); return; }   // nextScale = (8 - 8) % 256 = 0 at j = 0: useDefaultScalingMatrixFlag
+        int last = 8;
+        for (int j = 0; j < n; j++) {
+            // the rest of the list equal to the last value: one delta that makes nextScale 0 ends the transmission
+            bool rest_equal = j > 0;
+            for (int k = j; k < n && rest_equal; k++) rest_equal = v[k] == last;
+            if (rest_equal) { int d = -last; if (d < -128) d += 256; bw.se(d); return; }
+            int d = (int)v[j] - last;
+            if (d > 127) d -= 256;
+            if (d < -128) d += 256;
+            bw.se(d);
+            last = v[j];
+        }
+    }
+    void write_list_set(BitWriter &bw, const ListSet &ls, int n_lists)
+    {
+        for (int i = 0; i < n_lists; i++) {
+            bw.bit(ls.state[i] != 0);
+            if (ls.state[i]) write_list(bw, ls.v[i], i < 6 ? 16 : 64, ls.state[i] == 2);
+        }
+    }
+    // The weights an Intra picture ends up with, RASTER order -- the generator's own reading of Table 7-2: walk each list's
+    // chain of fall-backs (set A: default, then "the list before"; set B: the sequence level instead of the default).
+    void effective_weights(uint8_t w4[3][16], uint8_t w8[64]) const
+    {
+        static const uint8_t dflt4[16] = {6, 13, 13, 20, 20, 20, 28, 28, 28, 28, 32, 32, 32, 37, 37, 42};
+        static const uint8_t dflt8[64] = {6,  10, 10, 13, 11, 13, 16, 16, 16, 16, 18, 18, 18, 18, 18, 23, 23, 23, 23, 23, 23, 25,
+                                          25, 25, 25, 25, 25, 25, 27, 27, 27, 27, 27, 27, 27, 27, 29, 29, 29, 29, 29, 29, 29, 31,
+                                          31, 31, 31, 31, 31, 33, 33, 33, 33, 33, 36, 36, 36, 36, 38, 38, 38, 40, 40, 42};
+        auto seq_level = [&](int i, uint8_t *out) {   // Intra lists only: i = 0, 1, 2 (4x4) or 6 (8x8)
+            const int n = i < 6 ? 16 : 64;
+            if (!sps_lists.present) { memset(out, 16, (size_t)n); return; }
+            int k = i;
+            while (k != 0 && k != 6 && sps_lists.state[k] == 0) k--;          // Cb <- Y, Cr <- Cb
+            if (sps_lists.state[k] == 1) memcpy(out, sps_lists.v[k], (size_t)n);
+            else memcpy(out, i < 6 ? dflt4 : dflt8, (size_t)n);                // "use default", or fall-back rule A at the head
+        };
+        auto pic_level = [&](int i, uint8_t *out) {
+            const int n = i < 6 ? 16 : 64;
+            if (!pps_lists.present) { seq_level(i, out); return; }
+            int k = i;
+            const bool has8 = cfg.transform8x8 != 0;
+            auto st = [&](int q) { return (q >= 6 && !has8) ? 0 : pps_lists.state[q]; };
+            while (k != 0 && k != 6 && st(k) == 0) k--;
+            if (st(k) == 1) memcpy(out, pps_lists.v[k], (size_t)n);
+            else if (st(k) == 2) memcpy(out, i < 6 ? dflt4 : dflt8, (size_t)n);
+            else if (sps_lists.present) seq_level(k, out);                      // rule B: the sequence-level list of the head
+            else memcpy(out, i < 6 ? dflt4 : dflt8, (size_t)n);                // rule A
+        };
+        uint8_t z[64];
+        for (int pl = 0; pl < 3; pl++) {
+            pic_level(pl, z);
+            for (int k = 0; k < 16; k++) w4[pl][kZigzag4x4[k]] = z[k];
+        }
+        pic_level(6, z);
+        for (int k = 0; k < 64; k++) w8[kZigzag8x8[k]] = z[k];
     }
 
     // ---- parameter sets / slice ----
@@ -699,7 +881,11 @@ struct Gen {
         bw.bits(0, 8);           // constraint flags + reserved_zero_2bits
         bw.bits(40, 8);          // level_idc
         bw.ue(0);                // seq_parameter_set_id
-        if (cfg.profile_idc == 100) { bw.ue(1); bw.ue(0); bw.ue(0); bw.bit(0); bw.bit(0); }
+        if (cfg.profile_idc == 100) {
+            bw.ue(1); bw.ue(0); bw.ue(0); bw.bit(0);
+            if (cfg.scaling & 1) { bw.bit(1); write_list_set(bw, sps_lists, 8); }   // seq_scaling_matrix_present_flag
+            else bw.bit(0);
+        }
         bw.ue(0);                // log2_max_frame_num_minus4
         bw.ue(0);                // pic_order_cnt_type
         bw.ue(0);                // log2_max_pic_order_cnt_lsb_minus4
@@ -728,7 +914,12 @@ struct Gen {
         bw.bit(0);               // deblocking_filter_control_present_flag
         bw.bit(0);               // constrained_intra_pred_flag
         bw.bit(0);               // redundant_pic_cnt_present_flag
-        if (cfg.profile_idc == 100) { bw.bit(cfg.transform8x8); bw.bit(0); bw.se(cfg.cqp_offset[1]); }
+        if (cfg.profile_idc == 100) {
+            bw.bit(cfg.transform8x8);
+            if (cfg.scaling & 2) { bw.bit(1); write_list_set(bw, pps_lists, 6 + (cfg.transform8x8 ? 2 : 0)); }   // pic_scaling_matrix_present_flag
+            else bw.bit(0);
+            bw.se(cfg.cqp_offset[1]);
+        }
         bw.trailing();
         emit_nal(out, 3, 8, bw.bytes);
     }
@@ -736,40 +927,61 @@ struct Gen {
     void write_picture(std::vector<uint8_t> &out, int frame, uint8_t *packed)
     {
         m.init(W, H);
-        const int slice_qp = cfg.qp_min + rng.below(cfg.qp_max - cfg.qp_min + 1);
-        BitWriter bw;
-        bw.ue(0);                          // first_mb_in_slice
-        bw.ue(7);                          // slice_type: I (all slices of the picture)
-        bw.ue(0);                          // pic_parameter_set_id
-        bw.bits(0, 4);                     // frame_num
-        bw.ue((uint32_t)(frame & 0xffff)); // idr_pic_id
-        bw.bits(0, 4);                     // pic_order_cnt_lsb
-        bw.bit(0); bw.bit(0);              // no_output_of_prior_pics_flag, long_term_reference_flag
-        bw.se(slice_qp - 26);
-        CabacEnc enc(bw);
-        if (cfg.cabac) { while (!bw.aligned()) bw.bit(1); enc.init(slice_qp); }
-        int qp_prev = slice_qp;
+        const int N = W * H;
+        // slice starts: macroblock 0 and n_slices - 1 further distinct addresses (the reference's envelope: one slice)
+        std::vector<int> starts(1, 0);
+        const int want = cfg.n_slices < N ? cfg.n_slices : N;
+        while ((int)starts.size() < want) {
+            const int a = 1 + rng.below(N - 1);
+            bool dup = false;
+            for (int v : starts) dup |= v == a;
+            if (!dup) starts.push_back(a);
+        }
+        for (size_t i = 1; i < starts.size(); i++)
+            for (size_t k = i; k > 0 && starts[k] < starts[k - 1]; k--) { const int t = starts[k]; starts[k] = starts[k - 1]; starts[k - 1] = t; }
         MbSyntax s;
-        for (int mby = 0; mby < H; mby++)
-            for (int mbx = 0; mbx < W; mbx++) {
+        for (size_t sl = 0; sl < starts.size(); sl++) {
+            const int first = starts[sl], end = sl + 1 < starts.size() ? starts[sl + 1] : N;
+            m.cur_slice = (int)sl;
+            const int slice_qp = cfg.qp_min + rng.below(cfg.qp_max - cfg.qp_min + 1);
+            BitWriter bw;
+            bw.ue((uint32_t)first);            // first_mb_in_slice
+            bw.ue(7);                          // slice_type: I (all slices of the picture)
+            bw.ue(0);                          // pic_parameter_set_id
+            bw.bits(0, 4);                     // frame_num
+            bw.ue((uint32_t)(frame & 0xffff)); // idr_pic_id
+            bw.bits(0, 4);                     // pic_order_cnt_lsb
+            bw.bit(0); bw.bit(0);              // no_output_of_prior_pics_flag, long_term_reference_flag
+            bw.se(slice_qp - 26);
+            CabacEnc enc(bw);
+            if (cfg.cabac) { while (!bw.aligned()) bw.bit(1); enc.init(slice_qp); }
+            int qp_prev = slice_qp;
+            for (int addr = first; addr < end; addr++) {
+                const int mbx = addr % W, mby = addr / W;
+                m.slice[(size_t)addr] = (int)sl;
                 draw_mb(mbx, mby, qp_prev, s);
                 qp_prev = s.qp;
-                if (packed) fill_record(s, packed + (size_t)(mby * W + mbx) * MVHP_MB_BYTES);
+                if (packed) fill_record(s, packed + (size_t)addr * MVHP_MB_BYTES, mbx, mby);
                 if (cfg.cabac) {
                     write_mb_cabac(enc, mbx, mby, s);
-                    enc.terminate(mby == H - 1 && mbx == W - 1);
+                    enc.terminate(addr == end - 1);
                 } else {
                     write_mb_cavlc(bw, mbx, mby, s);
                 }
             }
-        if (!cfg.cabac) bw.trailing();
-        // (CABAC: EncodeFlush wrote the stop bit (the final "1") as part of terminate(1); pad to a byte)
-        else while (!bw.aligned()) bw.bit(0);
-        emit_nal(out, 3, 5, bw.bytes);
+            if (!cfg.cabac) bw.trailing();
+            // (CABAC: EncodeFlush wrote the stop bit (the final "1") as part of terminate(1); pad to a byte)
+            else while (!bw.aligned()) bw.bit(0);
+            emit_nal(out, 3, 5, bw.bytes);
+        }
     }
 };
 
 } // namespace
+
+namespace {
+size_t run_generator(const GenCfg &g, uint8_t *out, size_t cap, uint8_t *packed, uint8_t *weights);
+}
 
 extern "C" {
 
@@ -782,6 +994,19 @@ typedef struct mvgen_cfg {
     int32_t qp_min, qp_max, max_level;
 } mvgen_cfg_t;
 
+static GenCfg to_cfg(const mvgen_cfg_t *c)
+{
+    GenCfg g;
+    g.width_mbs = c->width_mbs; g.height_mbs = c->height_mbs; g.n_frames = c->n_frames; g.seed = c->seed;
+    g.profile_idc = c->profile_idc; g.cabac = c->cabac; g.transform8x8 = c->transform8x8; g.dense = c->dense;
+    g.cqp_offset[0] = c->cqp_offset_cb;
+    g.cqp_offset[1] = (c->profile_idc == 100) ? c->cqp_offset_cr : c->cqp_offset_cb;
+    g.sps_pps_every_frame = c->sps_pps_every_frame; g.allow_qp36_i16 = c->allow_qp36_i16;
+    g.qp_min = c->qp_min > 0 ? c->qp_min : 24; g.qp_max = c->qp_max >= g.qp_min ? c->qp_max : 32;
+    g.max_level = c->max_level > 0 ? c->max_level : 32;
+    return g;
+}
+
 // Returns the number of stream bytes (0 on bad config). Writes at most `cap` bytes to `out`
 // (call with out = NULL to size). `packed` (may be NULL) receives n_frames*W*H*800 bytes of
 // expected packed records.
@@ -792,15 +1017,44 @@ size_t mvgen_stream(const mvgen_cfg_t *c, uint8_t *out, size_t cap, uint8_t *pac
     if (c->profile_idc != 66 && c->profile_idc != 77 && c->profile_idc != 100) return 0;
     if (c->cabac && c->profile_idc == 66) return 0;
     if (c->transform8x8 && c->profile_idc != 100) return 0;
-    GenCfg g;
-    g.width_mbs = c->width_mbs; g.height_mbs = c->height_mbs; g.n_frames = c->n_frames; g.seed = c->seed;
-    g.profile_idc = c->profile_idc; g.cabac = c->cabac; g.transform8x8 = c->transform8x8; g.dense = c->dense;
-    g.cqp_offset[0] = c->cqp_offset_cb;
-    g.cqp_offset[1] = (c->profile_idc == 100) ? c->cqp_offset_cr : c->cqp_offset_cb;
-    g.sps_pps_every_frame = c->sps_pps_every_frame; g.allow_qp36_i16 = c->allow_qp36_i16;
-    g.qp_min = c->qp_min > 0 ? c->qp_min : 24; g.qp_max = c->qp_max >= g.qp_min ? c->qp_max : 32;
-    g.max_level = c->max_level > 0 ? c->max_level : 32;
+    GenCfg g = to_cfg(c);
+    return run_generator(g, out, cap, packed, nullptr);
+}
+
+// The same outside the reference's envelope (what MVHP_STREAM_SPEC decodes): n_slices slices per picture, pcm_permille / 1000
+// of the macroblocks I_PCM, scaling lists in the SPS (scaling & 1) and / or the PPS (scaling & 2; profile 100 only).
+// `weights` (may be NULL) receives the 112 bytes a correct decoder must report in mvhp_stream_params_t::scaling4 / scaling8.
+__attribute__((visibility("default")))
+size_t mvgen_stream_ex(const mvgen_cfg_t *c, int32_t n_slices, int32_t pcm_permille, int32_t scaling, uint8_t *out, size_t cap,
+                       uint8_t *packed, uint8_t *weights)
+{
+    if (!c || c->width_mbs <= 0 || c->height_mbs <= 0 || c->n_frames <= 0) return 0;
+    if (c->profile_idc != 66 && c->profile_idc != 77 && c->profile_idc != 100) return 0;
+    if (c->cabac && c->profile_idc == 66) return 0;
+    if (c->transform8x8 && c->profile_idc != 100) return 0;
+    if (scaling && c->profile_idc != 100) return 0;
+    if (n_slices < 1 || pcm_permille < 0 || pcm_permille > 1000) return 0;
+    GenCfg g = to_cfg(c);
+    g.n_slices = n_slices;
+    g.pcm_permille = pcm_permille;
+    g.scaling = scaling;
+    return run_generator(g, out, cap, packed, weights);
+}
+
+} // extern "C"
+
+namespace {
+size_t run_generator(const GenCfg &g, uint8_t *out, size_t cap, uint8_t *packed, uint8_t *weights)
+{
     Gen gen(g);
+    if (g.scaling & 1) gen.draw_lists(gen.sps_lists, 8);
+    if (g.scaling & 2) gen.draw_lists(gen.pps_lists, 6 + (g.transform8x8 ? 2 : 0));
+    if (weights) {
+        uint8_t w4[3][16], w8[64];
+        gen.effective_weights(w4, w8);
+        memcpy(weights, w4, 48);
+        memcpy(weights + 48, w8, 64);
+    }
     std::vector<uint8_t> s;
     const size_t pf = (size_t)g.width_mbs * g.height_mbs * MVHP_MB_BYTES;
     for (int f = 0; f < g.n_frames; f++) {
@@ -811,5 +1065,4 @@ size_t mvgen_stream(const mvgen_cfg_t *c, uint8_t *out, size_t cap, uint8_t *pac
     if (out) memcpy(out, s.data(), s.size() < cap ? s.size() : cap);
     return s.size();
 }
-
-} // extern "C"
+} // namespace

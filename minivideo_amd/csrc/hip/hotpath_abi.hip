@@ -181,6 +181,9 @@ MVHP_EXPORT int mvhp_set_fused_color(mvhp_ctx_t *c, int on)
 static int pick_layout(const mvhp_ctx *c, const mvhp_stream_params_t *p, int n_frames)
 {
     int layout = c->layout;
+    // pictures of several slices and scaling matrices (MVHP_STREAM_SPEC streams): the one-picture kernel,
+    // where a neighbour's availability is a per-wavefront scalar and LevelScale is a table in LDS -- whatever was asked for
+    if (p->flags & (MVHP_PARAM_SLICES | MVHP_PARAM_SCALING)) return MVHP_LAYOUT_ROWS;
     if (layout == MVHP_LAYOUT_AUTO) {
         // speed only.  A launch is a number of "rounds" of one workgroup per CU (the batch kernels fill a CU with one
         // workgroup); measured on 1080p, in units of one full round of the four-picture kernel (5.4 ms for 4 * CUs
@@ -265,6 +268,14 @@ static int launch_all(mvhp_ctx *c, const mvhp_stream_params_t *p, const void *d_
         a.cqp_off_cr = p->second_chroma_qp_index_offset;
         a.n_frames = n_frames;
         a.dc_shift_from = (p->flags & MVHP_PARAM_SPEC_LUMA_DC) ? 36 : 37;
+        a.slices = (p->flags & MVHP_PARAM_SLICES) ? 1 : 0;
+        a.scaling = (p->flags & MVHP_PARAM_SCALING) ? 1 : 0;
+        if (a.scaling) {
+            memcpy(a.weights, p->scaling4, 48);
+            memcpy(a.weights + 48, p->scaling8, 64);
+        } else {
+            memset(a.weights, 16, sizeof(a.weights));
+        }
         const int layout = pick_layout(c, p, n_frames);
         const int nw = pick_waves(c, p, n_frames, layout);
         c->last_layout = layout;

@@ -16,6 +16,10 @@ struct ReconArgs {
     int            n_frames;
     int            dc_shift_from;   // Intra16x16 luma DC takes the left-shift branch from this qP on: 37 = the reference's
                                     // `qP > 36` (h264_transform.c:797), 36 = the standard (MVHP_PARAM_SPEC_LUMA_DC)
+    // SURVEY 8f row f4 (MVHP_STREAM_SPEC streams; the one-picture-per-workgroup kernel only -- the launcher routes there):
+    int            slices;          // MVHP_PARAM_SLICES: mvhp_mb_header_t::unavail is honoured
+    int            scaling;         // MVHP_PARAM_SCALING: weights[] below instead of Flat_4x4_16 / Flat_8x8_16
+    uint8_t        weights[112];    // scaling4[3][16] | scaling8[64], raster order
 };
 
 struct ExpandArgs {

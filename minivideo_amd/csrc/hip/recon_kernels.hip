@@ -1,7 +1,7 @@
 // recon_kernels.hip -- hand-written CDNA4 (gfx950) kernels for the H.264 intra
 // reconstruction hot path.  Integer stencil work: no MFMA, HBM/LDS-latency bound.
 //
-//   recon_rows_kernel<NW>   replaces intra_prediction_process()
+//   recon_rows_kernel<NW, EXT> replaces intra_prediction_process()
 //                           (decoder/h264/h264_intra_prediction.c:112-145) for a
 //                           whole picture: all prediction modes, dequantisation,
 //                           4x4/8x8 IDCT, DC transforms, residual add + clip and
@@ -52,6 +52,8 @@ struct __attribute__((aligned(16))) BlockLds {
     int     ls4[18];       // LevelScale4x4 classes, 16*normAdjust (h264.c:427-435)
     int     ls8[36];       // LevelScale8x8 classes (h264.c:438-446)
     uint8_t cls8[64];      // 8x8 position -> class
+    uint8_t w4[3][16];     // weight matrices (raster), 16 = flat: LevelScale = weight * normAdjust (h264_transform.c:645-741)
+    uint8_t w8[64];
     uint32_t tap4[2 * 9 * 16]; // Intra4x4: [up-right unavailable][mode][sample] -> three byte offsets into the tile
     uint32_t tap8[9 * 64];     // Intra8x8: [mode][sample] -> three indices into the filtered edge array E8
 };
@@ -67,6 +69,9 @@ struct PairCtl {
     int dc_shift_from;   // ReconArgs::dc_shift_from
 };
 
+// SCALING: the weights of BlockLds::w4 / w8 are not all 16 (MVHP_PARAM_SCALING; its own instantiation, so that the flat
+// case keeps its three-class LevelScale in three registers)
+template <bool SCALING>
 __device__ __forceinline__ void residual_pair(WaveLds &W, const BlockLds &B, int lane, const int4 cA, const int4 cB,
                                               const PairCtl &pc)
 {
@@ -86,15 +91,18 @@ __device__ __forceinline__ void residual_pair(WaveLds &W, const BlockLds &B, int
                 const int row = r0 + h;
                 int d[8];
                 unpack8(h ? cB : cA, d);
+                // LevelScale8x8: 16 * normAdjust, or weight * normAdjust (SCALING)
+                auto ls8 = [&](int j) {
+                    const int v = B.ls8[m * 6 + B.cls8[row * 8 + j]];
+                    return SCALING ? (v >> 4) * (int)B.w8[row * 8 + j] : v;
+                };
                 if (qpy > 35) {
 #pragma unroll
-                    for (int j = 0; j < 8; j++)
-                        d[j] = (int)((unsigned)(d[j] * B.ls8[m * 6 + B.cls8[row * 8 + j]]) << ((s - 6) & 31));
+                    for (int j = 0; j < 8; j++) d[j] = (int)((unsigned)(d[j] * ls8(j)) << ((s - 6) & 31));
                 } else {
                     const int rnd = 1 << ((5 - s) & 31), sh = (6 - s) & 31;
 #pragma unroll
-                    for (int j = 0; j < 8; j++)
-                        d[j] = (d[j] * B.ls8[m * 6 + B.cls8[row * 8 + j]] + rnd) >> sh;
+                    for (int j = 0; j < 8; j++) d[j] = (d[j] * ls8(j) + rnd) >> sh;
                 }
                 if (row == 0) d[0] += 32; // rounding term of the final (m + 32) >> 6, see idct4x4
                 idct8_1d(d);
@@ -137,7 +145,19 @@ __device__ __forceinline__ void residual_pair(WaveLds &W, const BlockLds &B, int
         const int qpc = (b >= 20) ? (sel ? pc.qpc_cr[1] : pc.qpc_cr[0]) : (sel ? pc.qpc_cb[1] : pc.qpc_cb[0]);
         const int qP = chroma ? qpc : qpy;
         const int m = qP % 6, s = qP / 6;
-        const int lsA = B.ls4[m * 3 + 0], lsB = B.ls4[m * 3 + 1], lsC = B.ls4[m * 3 + 2];
+        int lsA = B.ls4[m * 3 + 0];
+        const int lsB = B.ls4[m * 3 + 1], lsC = B.ls4[m * 3 + 2];
+        int lsw[16];   // SCALING: LevelScale4x4 per position = weight * normAdjust (plane: Y / Cb / Cr)
+        if (SCALING) {
+            const uint8_t *w = B.w4[chroma ? ((b >= 20) ? 2 : 1) : 0];
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const int r = i >> 2, c = i & 3;
+                const int ls = ((r & 1) == 0 && (c & 1) == 0) ? lsA : (((r & 1) && (c & 1)) ? lsB : lsC);
+                lsw[i] = (ls >> 4) * (int)w[i];
+            }
+            lsA = lsw[0];   // the DC transforms use LevelScale(qP % 6, 0, 0) of their plane (8.5.10, 8.5.11.2)
+        }
         int dc = d[0];
         const bool keep_dc = chroma || (kind == MVHP_KIND_I16x16);
         if (chroma) {
@@ -168,7 +188,7 @@ __device__ __forceinline__ void residual_pair(WaveLds &W, const BlockLds &B, int
 #pragma unroll
             for (int i = 0; i < 16; i++) {
                 const int r = i >> 2, c = i & 3;
-                const int ls = ((r & 1) == 0 && (c & 1) == 0) ? lsA : (((r & 1) && (c & 1)) ? lsB : lsC);
+                const int ls = SCALING ? lsw[i] : (((r & 1) == 0 && (c & 1) == 0) ? lsA : (((r & 1) && (c & 1)) ? lsB : lsC));
                 d[i] = (int)((unsigned)(d[i] * ls) << shl);
             }
         } else {
@@ -176,7 +196,7 @@ __device__ __forceinline__ void residual_pair(WaveLds &W, const BlockLds &B, int
 #pragma unroll
             for (int i = 0; i < 16; i++) {
                 const int r = i >> 2, c = i & 3;
-                const int ls = ((r & 1) == 0 && (c & 1) == 0) ? lsA : (((r & 1) && (c & 1)) ? lsB : lsC);
+                const int ls = SCALING ? lsw[i] : (((r & 1) == 0 && (c & 1) == 0) ? lsA : (((r & 1) && (c & 1)) ? lsB : lsC));
                 d[i] = (int)((unsigned)((d[i] * ls + rnd) >> shr) << shl);
             }
         }
@@ -482,7 +502,9 @@ __device__ __forceinline__ void predict_chroma(WaveLds &W, int lane, int mode, b
 // ---------------------------------------------------------------------------
 // the reconstruction kernel
 // ---------------------------------------------------------------------------
-template <int NW>
+// EXT: pictures of several slices and / or scaling matrices (MVHP_PARAM_SLICES, MVHP_PARAM_SCALING: MVHP_STREAM_SPEC streams,
+// SURVEY 8f row f4) -- an instantiation of its own; the ordinary one is the round-2 kernel plus the I_PCM copy.
+template <int NW, bool EXT>
 __global__ __launch_bounds__(NW * 64) void recon_rows_kernel(ReconArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -514,6 +536,8 @@ __global__ __launch_bounds__(NW * 64) void recon_rows_kernel(ReconArgs a)
     for (int i = threadIdx.x; i < 2 * 9 * 16; i += NW * 64)
         B.tap4[i] = tap4_entry((i >> 4) % 9, i & 3, (i >> 2) & 3, i >= 9 * 16);
     for (int i = threadIdx.x; i < 9 * 64; i += NW * 64) B.tap8[i] = tap8_entry(i >> 6, i & 7, (i >> 3) & 7);
+    if (EXT)
+        for (int i = threadIdx.x; i < 112; i += NW * 64) (&B.w4[0][0])[i] = a.scaling ? a.weights[i] : (uint8_t)16;   // w4 | w8 are adjacent
     if (threadIdx.x < 16) B.progress[threadIdx.x] = 0;
     if (threadIdx.x == 16) B.abort_flag = 0;
     __syncthreads();
@@ -625,7 +649,7 @@ __global__ __launch_bounds__(NW * 64) void recon_rows_kernel(ReconArgs a)
                 pc.need[k] = (rl[k] || rc[k]) && (k < npair);
             }
             pc.dc_shift_from = a.dc_shift_from;
-            if (pc.need[0] || pc.need[1]) residual_pair(Wv, B, lane_p, cA, cB, pc);
+            if (pc.need[0] || pc.need[1]) residual_pair<EXT>(Wv, B, lane_p, cA, cB, pc);
 
 #pragma unroll 1
             for (int k = 0; k < npair; k++) {
@@ -642,10 +666,15 @@ __global__ __launch_bounds__(NW * 64) void recon_rows_kernel(ReconArgs a)
             const int cmode = (h0 >> 24) & 255, i16mode = h1 & 255;
             const bool res_luma = k ? rl[1] : rl[0], res_chroma = k ? rc[1] : rc[0];
             const int16_t *res = Wv.res[k];
-            const bool A = mbx > 0, C = Bv && (mbx < W - 1), D = A && Bv;
+            // neighbours: by geometry (h264_spatial.c:333-416), less those in another slice (MVHP_PARAM_SLICES: header byte 6)
+            const uint32_t un = (EXT && a.slices) ? ((h1 >> 16) & 255u) : 0u;
+            const bool BvG = Bv;   // the row above exists: what the wait and the fetch below go by
+            const bool A = (mbx > 0) && !(un & MVHP_UNAVAIL_A), C = BvG && (mbx < W - 1) && !(un & MVHP_UNAVAIL_C),
+                       D = (mbx > 0) && BvG && !(un & MVHP_UNAVAIL_D);
+            const bool Bv = BvG && !(un & MVHP_UNAVAIL_B);
 
             // ---- wait for the row above: needs columns <= min(mbx+1, W-1) ----
-            if (Bv) {
+            if (BvG) {
                 const int need = up_base + min(mbx + 2, W);
                 int spins = 0;
                 while (__hip_atomic_load(&B.progress[up_wave], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < need) {
@@ -657,11 +686,31 @@ __global__ __launch_bounds__(NW * 64) void recon_rows_kernel(ReconArgs a)
                 }
                 asm volatile("" ::: "memory");
                 // top neighbours: luma 16 + 8 up-right (when C), chroma 8 + 8
-                if (lane < 10 && (C || (lane >> 1) != 2))
+                if (lane < 10 && ((mbx < W - 1) || (lane >> 1) != 2))
                     *reinterpret_cast<uint32_t *>(top_dst) = *reinterpret_cast<const uint32_t *>(top_src + mbx * top_mul);
             }
             WAVE_SYNC();
 
+            if (kind == MVHP_KIND_IPCM) {
+                // I_PCM (8.3.5; MVHP_STREAM_SPEC streams only): the samples as they are.  Record layout (minivideo_hotpath.h):
+                // the owner of luma block 2j holds luma rows 2j and 2j+1, the owner of block 2j+1 Cb row j and Cr row j.
+                // (read again from the record -- a rare path; keeping the prefetched registers alive for it would cost every
+                //  macroblock eight registers and the kernel a wave per SIMD)
+                if (lane < 16) {
+                    const int jj = lane >> 1;
+                    const uint8_t *src = fpacked + (size_t)(row * W + mbx) * MVHP_MB_BYTES + MVHP_MB_HEADER_BYTES + lane * 32;
+                    const int4 sA = *reinterpret_cast<const int4 *>(src);
+                    if ((lane & 1) == 0) {
+                        const int4 sB = *reinterpret_cast<const int4 *>(src + 16);
+                        *reinterpret_cast<int4 *>(&Wv.T[(2 * jj + 1) * 32 + 16]) = sA;
+                        *reinterpret_cast<int4 *>(&Wv.T[(2 * jj + 2) * 32 + 16]) = sB;
+                    } else {
+                        *reinterpret_cast<int2 *>(&Wv.TC[0][(jj + 1) * 16 + 8]) = make_int2(sA.x, sA.y);
+                        *reinterpret_cast<int2 *>(&Wv.TC[1][(jj + 1) * 16 + 8]) = make_int2(sA.z, sA.w);
+                    }
+                }
+                WAVE_SYNC();
+            } else {
             // ---- luma ----
             if (kind == MVHP_KIND_I16x16) {
                 predict_16x16(Wv, lane, i16mode, A, Bv, res_luma, res);
@@ -673,6 +722,7 @@ __global__ __launch_bounds__(NW * 64) void recon_rows_kernel(ReconArgs a)
             }
             // ---- chroma ----
             predict_chroma(Wv, lane, cmode, A, Bv, res_chroma, res);
+            }
 
             // ---- write-out: the macroblock joins a 4-macroblock output strip in LDS; full strips go to HBM
             //      as 64-byte luma / 32-byte chroma row segments plus (fused) the RGB conversion ----
@@ -790,30 +840,25 @@ size_t recon_lds_bytes(int width_mbs, int nw)
     return sizeof(BlockLds) + (size_t)width_mbs * 32 + (size_t)nw * sizeof(WaveLds);
 }
 
+template <int NW, bool EXT>
+static hipError_t launch_rows_one(const ReconArgs &a, int n_frames, size_t lds, hipStream_t stream)
+{
+    hipError_t e = hipFuncSetAttribute((const void *)recon_rows_kernel<NW, EXT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((recon_rows_kernel<NW, EXT>), dim3(n_frames), dim3(NW * 64), lds, stream, a);
+    return hipGetLastError();
+}
+
 hipError_t launch_recon(const ReconArgs &a, int n_frames, int nw, hipStream_t stream)
 {
     const size_t lds = recon_lds_bytes(a.width_mbs, nw);
-    hipError_t e = hipSuccess;
+    const bool ext = a.slices || a.scaling;
     switch (nw) {
-    case 4:
-        e = hipFuncSetAttribute((const void *)recon_rows_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(recon_rows_kernel<4>, dim3(n_frames), dim3(4 * 64), lds, stream, a);
-        break;
-    case 8:
-        e = hipFuncSetAttribute((const void *)recon_rows_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(recon_rows_kernel<8>, dim3(n_frames), dim3(8 * 64), lds, stream, a);
-        break;
-    case 16:
-        e = hipFuncSetAttribute((const void *)recon_rows_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(recon_rows_kernel<16>, dim3(n_frames), dim3(16 * 64), lds, stream, a);
-        break;
-    default:
-        return hipErrorInvalidValue;
+    case 4: return ext ? launch_rows_one<4, true>(a, n_frames, lds, stream) : launch_rows_one<4, false>(a, n_frames, lds, stream);
+    case 8: return ext ? launch_rows_one<8, true>(a, n_frames, lds, stream) : launch_rows_one<8, false>(a, n_frames, lds, stream);
+    case 16: return ext ? launch_rows_one<16, true>(a, n_frames, lds, stream) : launch_rows_one<16, false>(a, n_frames, lds, stream);
+    default: return hipErrorInvalidValue;
     }
-    return hipGetLastError();
 }
 
 hipError_t launch_color(const ColorArgs &a, hipStream_t stream)

@@ -171,7 +171,11 @@ __global__ __launch_bounds__(NW * 64) void recon_oct_kernel(ReconArgs a)
     // largest supported size exceed 4 GiB of RGB: the launcher falls back to the quad kernel beyond 512 Ki macroblocks)
     const int o_c = lane_c >> 3;
     const int frame_raw = (int)blockIdx.x * 8 + o_c;
+#if defined(MVHP_ABL_NO_STORES)   // measurement build: everything but the global stores (pictures are not written)
+    const bool valid = false;
+#else
     const bool valid = frame_raw < a.n_frames;            // a short last workgroup repeats the last picture, stores off
+#endif
     const int frame = min(frame_raw, a.n_frames - 1);
     const uint32_t qf = (uint32_t)(frame - (int)blockIdx.x * 8);
     const uint8_t *gpacked = a.packed + (size_t)blockIdx.x * 8 * W * H * MVHP_MB_BYTES;
@@ -493,47 +497,49 @@ MVHP_MARK("r_4x4_end");
             // =====================================================================================
             MVHP_MARK("pred_chroma");
             {
+                // Branch-free over the modes (round 3).  The eight pictures of a wavefront rarely agree on the mode, so every
+                // mode's code ran anyway -- one after the other, each behind its own LDS round trip (the section cost a wave
+                // 1250 cycles per step, of which 165 instructions).  Now: the edges are read once, every mode's words are masked by
+                // "this lane's mode, and the neighbours it needs exist" (else the prediction stays 0,
+                // h264_intra_prediction.c:2157-2323), and OR-ed; only Plane, the long one, is skipped when no picture wants it.
                 const int pl = j >> 2, k = j & 3;
                 const int cx = (k & 1) * 4, cy = (k >> 1) * 4;
                 uint8_t *TCp = Q.TC[pl];
-                uint32_t pw[4] = {0u, 0u, 0u, 0u};
-                const uint32_t topw = *reinterpret_cast<const uint32_t *>(&TCp[8 + cx]);
-                const uint32_t lefw = *reinterpret_cast<const uint32_t *>(&Q.LcolC[pl][cy]);
-                if (cmode == 0) {
-                    const int bx = k & 1, by = k >> 1;
-                    const int sH = sum4(topw), sV = sum4(lefw);
-                    int v;
-                    if (!A && !Bv) v = 128;
-                    else if (bx == by) {
-                        if (A && Bv) v = (sH + sV + 4) >> 3;
-                        else if (A) v = (sV + 2) >> 2;
-                        else v = (sH + 2) >> 2;
-                    } else if (bx == 1) { // xO > 0, yO == 0: prefers top
-                        v = Bv ? ((sH + 2) >> 2) : ((sV + 2) >> 2);
-                    } else {              // xO == 0, yO > 0: prefers left
-                        v = A ? ((sV + 2) >> 2) : ((sH + 2) >> 2);
-                    }
-                    pw[0] = pw[1] = pw[2] = pw[3] = (uint32_t)v * 0x01010101u;
-                } else if (cmode == 1) {
-                    if (A) {
+                const uint2 topv = *reinterpret_cast<const uint2 *>(&TCp[8]);         // p[0..7, -1]
+                const uint2 lefv = *reinterpret_cast<const uint2 *>(Q.LcolC[pl]);     // p[-1, 0..7]
+                const uint32_t cor = TCp[7];
+                const uint32_t sA = A ? ~0u : 0u, sB = Bv ? ~0u : 0u;                 // (scalars)
+                const uint32_t mD = (cmode == 0) ? ~0u : 0u;
+                const uint32_t mH = ((cmode == 1) ? ~0u : 0u) & sA;
+                const uint32_t mV = ((cmode == 2) ? ~0u : 0u) & sB;
+                const uint32_t mP = ((cmode == 3) ? ~0u : 0u) & sA & sB;
+                const uint32_t topw = (k & 1) ? topv.y : topv.x;
+                const uint32_t lefw = (k & 2) ? lefv.y : lefv.x;
+                // Intra_Chroma_DC (:2338-2441): which sums a block uses depends on its position and on which neighbours
+                // exist -- the latter is the same for the eight pictures (scalar branches)
+                const int sH = sum4(topw), sV = sum4(lefw);
+                int dcv;
+                if (A && Bv) {
+                    const bool both = (k == 0) || (k == 3);
+                    const int one = (k == 1) ? sH : sV;               // block 1 prefers the top, block 2 the left
+                    dcv = both ? ((sH + sV + 4) >> 3) : ((one + 2) >> 2);
+                } else if (A) dcv = (sV + 2) >> 2;
+                else if (Bv) dcv = (sH + 2) >> 2;
+                else dcv = 128;
+                const uint32_t fix = (topw & mV) | (((uint32_t)dcv * 0x01010101u) & mD);
+                const uint32_t lh = lefw & mH;
+                uint32_t pw[4];
 #pragma unroll
-                        for (int y = 0; y < 4; y++) pw[y] = ((lefw >> (8 * y)) & 255u) * 0x01010101u;
-                    }
-                } else if (cmode == 2) {
-                    if (Bv) pw[0] = pw[1] = pw[2] = pw[3] = topw;
-                } else if (cmode == 3) {
-                    if (A && Bv) {
-                        const uint2 topv = *reinterpret_cast<const uint2 *>(&TCp[8]);
-                        const uint2 lefv = *reinterpret_cast<const uint2 *>(Q.LcolC[pl]);
-                        const int cor = TCp[7];
-                        const int Hh = plane_grad8(topv, (uint32_t)cor), Vv = plane_grad8(lefv, (uint32_t)cor);
-                        const int aa = 16 * ((int)(lefv.y >> 24) + (int)(topv.y >> 24));
-                        const int bb = (34 * Hh + 32) >> 6;
-                        const int cc = (34 * Vv + 32) >> 6;
-                        const int v00 = aa + bb * (cx - 3) + cc * (cy - 3) + 16;
+                for (int y = 0; y < 4; y++) pw[y] = fix | __builtin_amdgcn_perm(lh, lh, 0x01010101u * (uint32_t)y);
+                if (__builtin_amdgcn_ballot_w64(mP != 0u) != 0) {   // some picture predicts Plane (:2524-2564)
+                    const int Hh = plane_grad8(topv, cor), Vv = plane_grad8(lefv, cor);
+                    const int aa = 16 * ((int)(lefv.y >> 24) + (int)(topv.y >> 24));
+                    const int bb = ((34 * Hh + 32) >> 6) & (int)mP;
+                    const int cc = ((34 * Vv + 32) >> 6) & (int)mP;
+                    // the other lanes: gradient 0 and a value far below zero -> every sample clips to 0
+                    const int v00 = (int)(((uint32_t)(aa + bb * (cx - 3) + cc * (cy - 3) + 16) & mP) | (0x80000000u & ~mP));
 #pragma unroll
-                        for (int y = 0; y < 4; y++) pw[y] = plane_row(v00 + cc * y, bb);
-                    }
+                    for (int y = 0; y < 4; y++) pw[y] |= plane_row(v00 + cc * y, bb);
                 }
                 emit_block_ypairs(&TCp[(cy + 1) * 16 + 8 + cx], 16, pw, c2);
             }
@@ -545,46 +551,49 @@ MVHP_MARK("r_4x4_end");
             if (kind == MVHP_KIND_I16x16) {
                 // h264_intra_prediction.c:1809-2141 + transform16x16_luma; lane j predicts its own two 4x4 blocks
 MVHP_MARK("p_i16");
-                uint32_t pw[2][4] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
-                if (i16mode == 0) {
-                    if (Bv) {
-                        const uint2 t = *reinterpret_cast<const uint2 *>(&Q.T[16 + xO0]);
-                        pw[0][0] = pw[0][1] = pw[0][2] = pw[0][3] = t.x;
-                        pw[1][0] = pw[1][1] = pw[1][2] = pw[1][3] = t.y;
-                    }
-                } else if (i16mode == 1) {
-                    if (A) {
-                        const uint32_t l = *reinterpret_cast<const uint32_t *>(&Q.Lcol[yO]);
+                // Branch-free over the modes, like the chroma prediction above (this section cost a wave 3100 cycles per step with
+                // the four modes as four branches, 1000 when the eight pictures happened to agree): edges once, masked words OR-ed
+                // (a mode whose neighbours are missing predicts 0, h264_intra_prediction.c:1868-1932), Plane skipped when unused.
+                const uint4 topv = *reinterpret_cast<const uint4 *>(&Q.T[16]);     // p[0..15, -1]
+                const uint4 lefv = *reinterpret_cast<const uint4 *>(Q.Lcol);       // p[-1, 0..15]
+                const uint32_t lrow = *reinterpret_cast<const uint32_t *>(&Q.Lcol[yO]);
+                const uint32_t cor = Q.T[15];
+                const uint32_t sA = A ? ~0u : 0u, sB = Bv ? ~0u : 0u;              // (scalars)
+                const uint32_t mV = ((i16mode == 0) ? ~0u : 0u) & sB;
+                const uint32_t mH = ((i16mode == 1) ? ~0u : 0u) & sA;
+                const uint32_t mD = (i16mode == 2) ? ~0u : 0u;
+                const uint32_t mP = ((i16mode == 3) ? ~0u : 0u) & sA & sB;
+                const bool right = (j & 2) != 0;                                   // the lane's eight columns: 0-7 or 8-15
+                int sumH = (int)__builtin_amdgcn_sad_u8(topv.x, 0u, 0u), sumV = (int)__builtin_amdgcn_sad_u8(lefv.x, 0u, 0u);
+                sumH = (int)__builtin_amdgcn_sad_u8(topv.y, 0u, (uint32_t)sumH); sumV = (int)__builtin_amdgcn_sad_u8(lefv.y, 0u, (uint32_t)sumV);
+                sumH = (int)__builtin_amdgcn_sad_u8(topv.z, 0u, (uint32_t)sumH); sumV = (int)__builtin_amdgcn_sad_u8(lefv.z, 0u, (uint32_t)sumV);
+                sumH = (int)__builtin_amdgcn_sad_u8(topv.w, 0u, (uint32_t)sumH); sumV = (int)__builtin_amdgcn_sad_u8(lefv.w, 0u, (uint32_t)sumV);
+                int dcv;   // Intra_16x16_DC (:2017-2083): the variant is positional, the same for the eight pictures
+                if (A && Bv) dcv = (sumH + sumV + 16) >> 5;
+                else if (A) dcv = (sumV + 8) >> 4;
+                else if (Bv) dcv = (sumH + 8) >> 4;
+                else dcv = 128;
+                const uint32_t dcw = ((uint32_t)dcv * 0x01010101u) & mD;
+                const uint32_t fix0 = ((right ? topv.z : topv.x) & mV) | dcw, fix1 = ((right ? topv.w : topv.y) & mV) | dcw;
+                const uint32_t lh = lrow & mH;
+                uint32_t pw[2][4];
 #pragma unroll
-                        for (int y = 0; y < 4; y++) pw[0][y] = pw[1][y] = ((l >> (8 * y)) & 255u) * 0x01010101u;
-                    }
-                } else if (i16mode == 2) {
-                    const uint4 topv = *reinterpret_cast<const uint4 *>(&Q.T[16]);
-                    const uint4 lefv = *reinterpret_cast<const uint4 *>(Q.Lcol);
-                    const int sumH = sum4(topv.x) + sum4(topv.y) + sum4(topv.z) + sum4(topv.w);
-                    const int sumV = sum4(lefv.x) + sum4(lefv.y) + sum4(lefv.z) + sum4(lefv.w);
-                    int v;
-                    if (A && Bv) v = (sumH + sumV + 16) >> 5;
-                    else if (A) v = (sumV + 8) >> 4;
-                    else if (Bv) v = (sumH + 8) >> 4;
-                    else v = 128;
+                for (int y = 0; y < 4; y++) {
+                    const uint32_t hrow = __builtin_amdgcn_perm(lh, lh, 0x01010101u * (uint32_t)y);
+                    pw[0][y] = fix0 | hrow;
+                    pw[1][y] = fix1 | hrow;
+                }
+                if (__builtin_amdgcn_ballot_w64(mP != 0u) != 0) {   // some picture predicts Plane (:2096-2141)
+                    const int Hh = plane_grad16(topv, cor), Vv = plane_grad16(lefv, cor);
+                    const int aa = 16 * ((int)(lefv.w >> 24) + (int)(topv.w >> 24));
+                    const int bb = ((5 * Hh + 32) >> 6) & (int)mP;
+                    const int cc = ((5 * Vv + 32) >> 6) & (int)mP;
+                    // the other lanes: gradient 0 and a value far below zero -> every sample clips to 0
+                    const int v00 = (int)(((uint32_t)(aa + bb * (xO0 - 7) + cc * (yO - 7) + 16) & mP) | (0x80000000u & ~mP));
 #pragma unroll
-                    for (int y = 0; y < 4; y++) pw[0][y] = pw[1][y] = (uint32_t)v * 0x01010101u;
-                } else if (i16mode == 3) {
-                    if (A && Bv) {
-                        const uint4 topv = *reinterpret_cast<const uint4 *>(&Q.T[16]);
-                        const uint4 lefv = *reinterpret_cast<const uint4 *>(Q.Lcol);
-                        const int cor = Q.T[15];
-                        const int Hh = plane_grad16(topv, (uint32_t)cor), Vv = plane_grad16(lefv, (uint32_t)cor);
-                        const int aa = 16 * ((int)(lefv.w >> 24) + (int)(topv.w >> 24));
-                        const int bb = (5 * Hh + 32) >> 6;
-                        const int cc = (5 * Vv + 32) >> 6;
-                        const int v00 = aa + bb * (xO0 - 7) + cc * (yO - 7) + 16;
-#pragma unroll
-                        for (int y = 0; y < 4; y++) {
-                            pw[0][y] = plane_row(v00 + cc * y, bb);
-                            pw[1][y] = plane_row(v00 + cc * y + 4 * bb, bb);
-                        }
+                    for (int y = 0; y < 4; y++) {
+                        pw[0][y] |= plane_row(v00 + cc * y, bb);
+                        pw[1][y] |= plane_row(v00 + cc * y + 4 * bb, bb);
                     }
                 }
                 emit_block_ypairs(&Q.T[(yO + 1) * 32 + 16 + xO0], 32, pw[0], r2[0]);
@@ -791,6 +800,18 @@ MVHP_MARK("p_i8");
 MVHP_MARK("p_i8_end");
             }
             WAVE_SYNC();
+            // I_PCM (8.3.5; only MVHP_STREAM_SPEC streams carry it): the samples as they are, over whatever
+            // the prediction paths above made of such a record.  Record layout (minivideo_hotpath.h): the lane's 64 bytes hold
+            // luma rows 2j and 2j+1, Cb row j, Cr row j.
+            if (__builtin_amdgcn_ballot_w64(kind == MVHP_KIND_IPCM) != 0) {
+                if (kind == MVHP_KIND_IPCM) {
+                    *reinterpret_cast<int4 *>(&Q.T[(2 * j + 1) * 32 + 16]) = make_int4(w[4].x, w[4].y, w[5].x, w[5].y);
+                    *reinterpret_cast<int4 *>(&Q.T[(2 * j + 2) * 32 + 16]) = make_int4(w[6].x, w[6].y, w[7].x, w[7].y);
+                    *reinterpret_cast<int2 *>(&Q.TC[0][(j + 1) * 16 + 8]) = make_int2(w[8].x, w[8].y);
+                    *reinterpret_cast<int2 *>(&Q.TC[1][(j + 1) * 16 + 8]) = make_int2(w[9].x, w[9].y);
+                }
+                WAVE_SYNC();
+            }
 
             // =====================================================================================
             // write-out (mb_to_rgb, export_utils.c:209-324, fused): park, or flush the 4-macroblock strip
@@ -874,7 +895,11 @@ MVHP_MARK("p_i8_end");
 #undef MVHP_ST
 #undef MVHP_ST_
 #undef MVHP_ST2
+#if defined(MVHP_ABL_NO_STORES)
+                        n_st = a.n_frames < 0 ? VM_STRIP : 0;   // (0 at run time; both forms of the wait stay in the code)
+#else
                         n_st = VM_STRIP;
+#endif
                     } else if (m_own <= mbi && valid) {
                         MVHP_MARK("wo_short");
                         // ---- short strip at the right picture edge (W % 4 != 0): compiler-counted stores ----

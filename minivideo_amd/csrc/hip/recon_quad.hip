@@ -634,6 +634,22 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_num_vgpr(100))) void
             }
 
             WAVE_SYNC();
+            // I_PCM (8.3.5; only MVHP_STREAM_SPEC streams carry it): the samples as they are, over whatever
+            // the prediction paths above made of such a record.  Record layout (minivideo_hotpath.h): the owner of luma block
+            // 2i holds luma rows 2i and 2i+1, the owner of block 2i+1 Cb row i and Cr row i.
+            if (__builtin_amdgcn_ballot_w64(kind == MVHP_KIND_IPCM) != 0) {
+                if (kind == MVHP_KIND_IPCM) {
+                    const int jp = j >> 1;
+                    if ((j & 1) == 0) {
+                        *reinterpret_cast<int4 *>(&Q.T[(2 * jp + 1) * 32 + 16]) = cLA;
+                        *reinterpret_cast<int4 *>(&Q.T[(2 * jp + 2) * 32 + 16]) = cLB;
+                    } else {
+                        *reinterpret_cast<int2 *>(&Q.TC[0][(jp + 1) * 16 + 8]) = make_int2(cLA.x, cLA.y);
+                        *reinterpret_cast<int2 *>(&Q.TC[1][(jp + 1) * 16 + 8]) = make_int2(cLA.z, cLA.w);
+                    }
+                }
+                WAVE_SYNC();
+            }
 
             // =====================================================================================
             // write-out (mb_to_rgb, export_utils.c:209-324, fused): park, or flush the 4-macroblock strip

@@ -10,7 +10,7 @@ here are hand-derived from the standard's text, the reference gives different an
   16 * 10 = 160; standard: dcY = (3 * 160) << (36/6 - 6) = 480; the block's only coefficient d00 = 480 -> every
   residual = (480 + 32) >> 6 = 8 -> 128 + 8 = 136.  (QP 35: (3*176 + 2^0) >> 1 = 264 -> (264+32)>>6 = 4 ... the
   reference-mode values 135 / 0 / 136 for QP 35 / 36 / 37 stay as SURVEY Appendix A recorded them.)
-* a picture of several slices is refused (the record format has no per-macroblock slice id for the availability rules)."""
+* pictures of several slices, scaling matrices and I_PCM: tests/test_spec_f4.py (round 3)."""
 import os
 
 import numpy as np
@@ -56,15 +56,23 @@ def test_spec_mode_reads_four_byte_streams_too():
         assert np.array_equal(a.packed(0)[1], b.packed(0)[1])
 
 
-def test_spec_mode_refuses_pictures_of_several_slices():
+def test_spec_mode_groups_slices_and_refuses_overlapping_ones():
+    """a second slice NAL with first_mb_in_slice > 0 belongs to the previous picture (round 3: decoded, tests/test_spec_f4.py);
+    here it claims macroblock 1, which the first slice has already decoded: the picture fails, it is not mis-decoded"""
     raw = np.fromfile(os.path.join(GOLDEN, "kat_cavlc_2mb.264"), np.uint8).tobytes().rstrip(b"\x00")
-    # a second slice NAL of the same picture: first_mb_in_slice = 1 ('010'), slice_type 7 ('0001000'), pps 0 ('1'),
-    # then arbitrary payload
+    # first_mb_in_slice = 1 ('010'), slice_type 7 ('0001000'), pps 0 ('1'), then arbitrary payload
     second = b"\x00\x00\x00\x01\x65" + bytes([0b01000010, 0b00110000, 0x80])
     with Stream(np.frombuffer(raw + second + bytes(64), np.uint8), spec=True) as s:
-        assert s.ok and s.idr_count == 1 and s.params(0) is None
+        assert s.ok and s.idr_count == 1
+        p = s.params(0)
+        assert p is not None and (p.flags & 4)                      # MVHP_PARAM_SLICES
         buf = np.zeros(2 * 800, np.uint8)
-        assert s.L.mvhp_stream_decode_packed(s.h, 0, buf.ctypes.data, buf.size) != 1 and "several slices" in s.error()
+        assert s.L.mvhp_stream_decode_packed(s.h, 0, buf.ctypes.data, buf.size) != 1
+        assert "does not start where the previous one ended" in s.error()
+        assert not buf.any()
+    # the reference's reading of the same bytes (default mode): the second NAL is a picture of its own, and broken
+    with Stream(np.frombuffer(raw + second + bytes(64), np.uint8)) as s:
+        assert s.idr_count == 2 and s.packed(0)[0] == 1 and s.packed(1)[0] != 1
 
 
 def test_oracle_luma_dc_rule_at_qp36():
