@@ -319,7 +319,7 @@ struct Gen {
             cand[nc++] = 0;
             if (A) cand[nc++] = 1;
             if (B) cand[nc++] = 2;
-            if (A && B) cand[nc++] = 3;
+            if (A && B && D) cand[nc++] = 3;   // Plane reads p[-1,-1] too (with one slice per picture A && B implies D)
             s.cmode = cand[rng.below(nc)];
         }
         // ---- residual ----
@@ -365,7 +365,7 @@ struct Gen {
             cand[nc++] = 2;
             if (B) cand[nc++] = 0;
             if (A) cand[nc++] = 1;
-            if (A && B) cand[nc++] = 3;
+            if (A && B && D) cand[nc++] = 3;
             i16mode = cand[rng.below(nc)];
             s.mb_type = 1 + i16mode + 4 * s.cbp_c + (s.cbp_l ? 12 : 0);
         }

@@ -380,7 +380,10 @@ __device__ __forceinline__ void predict_8x8(WaveLds &W, const BlockLds &B, int l
 }
 
 // Intra 16x16: 64 lanes x 4 samples. h264_intra_prediction.c:1809-2141 + transform16x16_luma.
-__device__ __forceinline__ void predict_16x16(WaveLds &W, int lane, int mode, bool A, bool Bv, bool has_res,
+// D: the up-left macroblock is available -- it always is when A and Bv are, except across a slice boundary, where the
+// reference's code reads the corner as 0 (h264_intra_prediction.c:1839-1846: phv stays 0); a conforming stream never
+// predicts Plane there
+__device__ __forceinline__ void predict_16x16(WaveLds &W, int lane, int mode, bool A, bool Bv, bool D, bool has_res,
                                               const int16_t *res)
 {
     const int y = lane >> 2, x0 = (lane & 3) * 4;
@@ -406,7 +409,7 @@ __device__ __forceinline__ void predict_16x16(WaveLds &W, int lane, int mode, bo
         p[0] = p[1] = p[2] = p[3] = v;
     } else if (mode == 3) {
         if (left && up) {
-            const int cor = W.T[15];
+            const int cor = D ? (int)W.T[15] : 0;
             const uint32_t tw[4] = {topv.x, topv.y, topv.z, topv.w};
             const uint32_t lw[4] = {lefv.x, lefv.y, lefv.z, lefv.w};
             int H = 0, V = 0;
@@ -440,7 +443,7 @@ __device__ __forceinline__ void predict_16x16(WaveLds &W, int lane, int mode, bo
 
 // Chroma, both planes: lane -> plane = lane>>5, y = (lane&31)>>2, x0 = (lane&3)*2.
 // h264_intra_prediction.c:2157-2564 + transform4x4_chroma.
-__device__ __forceinline__ void predict_chroma(WaveLds &W, int lane, int mode, bool A, bool Bv, bool has_res,
+__device__ __forceinline__ void predict_chroma(WaveLds &W, int lane, int mode, bool A, bool Bv, bool D, bool has_res,
                                                const int16_t *res)
 {
     const int pl = lane >> 5, y = (lane & 31) >> 2, x0 = (lane & 3) * 2;
@@ -470,7 +473,7 @@ __device__ __forceinline__ void predict_chroma(WaveLds &W, int lane, int mode, b
         if (up) { p0 = TC[8 + x0]; p1 = TC[8 + x0 + 1]; }
     } else if (mode == 3) {
         if (left && up) {
-            const int cor = TC[7];
+            const int cor = D ? (int)TC[7] : 0;
             const uint32_t tw[2] = {topv.x, topv.y}, lw[2] = {lefv.x, lefv.y};
             int H = 0, V = 0;
 #pragma unroll
@@ -713,7 +716,7 @@ __global__ __launch_bounds__(NW * 64) void recon_rows_kernel(ReconArgs a)
             } else {
             // ---- luma ----
             if (kind == MVHP_KIND_I16x16) {
-                predict_16x16(Wv, lane, i16mode, A, Bv, res_luma, res);
+                predict_16x16(Wv, lane, i16mode, A, Bv, D, res_luma, res);
             } else if (kind == MVHP_KIND_I4x4) {
                 predict_mb_4x4(Wv, B, lane, m0, m1, m2, m3, A, Bv, C, D, res_luma, res);
             } else {
@@ -721,7 +724,7 @@ __global__ __launch_bounds__(NW * 64) void recon_rows_kernel(ReconArgs a)
                     predict_8x8(Wv, B, lane, blk, (m0 >> (blk * 8)) & 255, A, Bv, C, D, res_luma, res);
             }
             // ---- chroma ----
-            predict_chroma(Wv, lane, cmode, A, Bv, res_chroma, res);
+            predict_chroma(Wv, lane, cmode, A, Bv, D, res_chroma, res);
             }
 
             // ---- write-out: the macroblock joins a 4-macroblock output strip in LDS; full strips go to HBM

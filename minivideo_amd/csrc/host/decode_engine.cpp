@@ -71,7 +71,9 @@ bool same_params(const mvhp_stream_params_t &a, const mvhp_stream_params_t &b)
 {
     return a.width_mbs == b.width_mbs && a.height_mbs == b.height_mbs &&
            a.chroma_qp_index_offset == b.chroma_qp_index_offset &&
-           a.second_chroma_qp_index_offset == b.second_chroma_qp_index_offset && a.flags == b.flags;
+           a.second_chroma_qp_index_offset == b.second_chroma_qp_index_offset && a.flags == b.flags &&
+           (!(a.flags & MVHP_PARAM_SCALING) ||
+            (memcmp(a.scaling4, b.scaling4, sizeof(a.scaling4)) == 0 && memcmp(a.scaling8, b.scaling8, sizeof(a.scaling8)) == 0));
 }
 
 struct Pinned {
@@ -311,7 +313,10 @@ int Engine::chunk_pictures(const mvhp_stream_params_t &p) const
 int Engine::batch_capacity(const mvhp_stream_params_t &p, int remaining) const
 {
     const int n_ctx = (int)ctx_.size();
-    int cap = opts_.batch_pictures > 0 ? opts_.batch_pictures : 1024;
+    // the cap: four pictures per CU (the four-picture kernel's full round); a long job -- from 4096 pictures per context on --
+    // runs its steady state in launches of 2048, eight per CU, which is what the eight-picture kernel wants (round 3: the
+    // product path reaches the kernel the bench times; the ramp and the taper stay as they are)
+    int cap = opts_.batch_pictures > 0 ? opts_.batch_pictures : ((n_order_ >= 4096 * n_ctx) ? 2048 : 1024);
     const size_t per_pic = compact_slot_bytes(p) + mvhp_packed_frame_bytes(&p) + mvhp_yuv_frame_bytes(&p) +
                            (want_rgb_ ? mvhp_rgb_frame_bytes(&p) : 0);
     size_t budget = ctx_[0].mem_budget;
@@ -321,7 +326,7 @@ int Engine::batch_capacity(const mvhp_stream_params_t &p, int remaining) const
     const int share = (remaining + n_ctx - 1) / n_ctx;
     if (opts_.batch_pictures > 0) return std::max(1, std::min(cap, share));   // an explicit batch size is taken as given
     const int round = next_batch_id_ / n_ctx;                                   // batches each context has been given so far
-    const int ramp = round < 5 ? (64 << round) : cap;
+    const int ramp = round < 6 ? std::min(64 << round, cap) : cap;
     const int taper = std::max(64, (int)((remaining * 0.35 + n_ctx - 1) / n_ctx));
     return std::max(1, std::min(std::min(cap, ramp), std::min(share, taper)));
 }
