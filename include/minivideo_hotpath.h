@@ -293,6 +293,14 @@ typedef struct mvhp_decode_stats {
     double   sink_s;               /* time inside the sink callback                                                  */
     uint64_t stream_bytes;         /* NAL bytes entropy-decoded                                                      */
     uint64_t h2d_bytes, d2h_bytes;
+    /* where a COLD call's time goes (an engine keeps its pools: the second call of the same shape allocates nothing)  */
+    double   host_alloc_s;         /* page-locking host memory (summed over the threads that did it)                 */
+    double   dev_alloc_s;          /* device allocations                                                             */
+    double   first_launch_s;       /* the first reconstruction call of each context: code-object load + first launch */
+    double   first_picture_s;      /* from the call to the first picture at the sink                                 */
+    uint64_t host_alloc_bytes, dev_alloc_bytes;
+    uint32_t placed_buffers;       /* 1: the device batch buffers come from mvhp_placed_alloc (MINIVIDEO_PLACED=1)   */
+    uint32_t reserved;
 } mvhp_decode_stats_t;
 
 /* Called on the calling thread, once per picture, in the order of `order`.  rc = MVHP_SUCCESS: yuv (and rgb when

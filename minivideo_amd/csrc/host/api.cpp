@@ -404,8 +404,12 @@ minivideo_EXPORT int minivideo_decode(MediaFile_t *m, const char *output_directo
     mvhp_engine_destroy(eng);
     if (getenv("MINIVIDEO_STATS"))
         fprintf(stderr, "[minivideo] decode: %u pictures entropy-decoded, %u written, %u failed, %u launches (largest %u pictures), "
-                        "%u contexts, %u host threads, %.3f s\n", st.pictures_issued, st.pictures_ok, st.pictures_failed, st.batches,
-                st.max_batch_pictures, st.contexts, st.host_threads, st.wall_s);
+                        "%u contexts, %u host threads, %.3f s (first picture after %.3f s; page-locking %.3f s for %.2f GB, device "
+                        "allocations %.3f s for %.2f GB, first launches %.3f s; entropy threads busy %.3f s, H2D %.3f s, kernels %.3f s, "
+                        "D2H %.3f s, sink %.3f s)\n", st.pictures_issued, st.pictures_ok, st.pictures_failed, st.batches,
+                st.max_batch_pictures, st.contexts, st.host_threads, st.wall_s, st.first_picture_s, st.host_alloc_s,
+                st.host_alloc_bytes / 1e9, st.dev_alloc_s, st.dev_alloc_bytes / 1e9, st.first_launch_s, st.entropy_busy_s, st.h2d_s,
+                st.kernel_s, st.d2h_s, st.sink_s);
     if (sink.aborted) return FAILURE;
     return sink.exported > 0 ? SUCCESS : FAILURE;   // all wanted pictures, or the stream ended after the last good IDR
 }
