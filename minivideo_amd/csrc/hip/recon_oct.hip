@@ -87,6 +87,7 @@ __device__ __forceinline__ int pack_res_shr6(int a, int b)
 
 __device__ __forceinline__ uint32_t lerp_u8(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_lerp(a, b, c); }
 
+
 #ifndef MVHP_I8_UNROLL
 #define MVHP_I8_UNROLL 4   // the four 8x8 blocks of an Intra8x8 macroblock as four copies: positions become constants (-31 % VALU,
                            // -78 % SALU in that loop; High 12.64 -> 12.05 ms); 1 = one loop body
