@@ -71,6 +71,8 @@ def parse_args():
     ap.add_argument("--ordinary-buffers", action="store_true",
                     help="allocate the batch buffers the ordinary way instead of mvhp_placed_alloc()")
     ap.add_argument("--host-threads", type=int, default=0, help="entropy threads per rank (0: host cores / ranks)")
+    ap.add_argument("--e2e-placed", action="store_true",
+                    help="the end-to-end leg's engine takes its batch buffers from a placed arena (MINIVIDEO_PLACED=1)")
     ap.add_argument("--engine-contexts", type=int, default=-1,
                     help="the single-process leg: ONE engine with this many contexts (one per device; more contexts than devices "
                          "share them = a rehearsal, never a result).  -1: --gpus when N > 1, 2 on one GPU (rehearsal); 0: skip")
@@ -243,7 +245,7 @@ def end_to_end(args, params, stream, n_distinct, rec, want_rgb, total, rank, wor
     if L.mvhp_stream_open(big.ctypes.data, big.size, C.byref(h)) != 1 or L.mvhp_stream_idr_count(h) != mine:
         raise SystemExit("bench: the end-to-end stream failed to parse")
     order = list(range(mine))
-    eng = Engine(contexts=1, host_threads=threads, batch_pictures=args.e2e_batch, first_device=local_rank)
+    eng = Engine(contexts=1, host_threads=threads, batch_pictures=args.e2e_batch, first_device=local_rank, placed=args.e2e_placed)
     check = sorted({0, 1, len(order) // 2, len(order) - 1} & set(range(len(order))))
     kept = {}
 

@@ -274,7 +274,8 @@ typedef struct mvhp_engine_opts {
     int32_t fail_context;    /* test hook: the first batch launched on this context reports a failure; -1 = off       */
     int32_t first_device;    /* context k runs on HIP device (first_device + k) % device count (one process per GPU:  */
                              /* contexts = 1, first_device = LOCAL_RANK)                                              */
-    int32_t reserved[2];
+    int32_t reserved[2];     /* [0] bit 0: the contexts' batch buffers come from one placed arena each (mvhp_placed_alloc_sets;
+                                also env MINIVIDEO_PLACED=1) -- for engines that live long: the arena takes seconds to get */
 } mvhp_engine_opts_t;
 
 typedef struct mvhp_decode_stats {
@@ -335,6 +336,12 @@ MVHP_EXPORT int  mvhp_probe_pair(int device, void *d_a, void *d_b, size_t bytes,
  * MVHP_FAILURE: not enough memory -- use ordinary allocations. */
 MVHP_EXPORT int  mvhp_placed_alloc(int device, int count, const size_t *bytes, size_t arena_bytes, void **d_ptrs, void **arena,
                                    int *groups_of, int *groups_found);
+/* The same for a pipeline's batch buffers: `sets` copies of `count` (<= 8) buffers, d_ptrs[s * count + i] = buffer i of set s;
+ * buffer i of every set lies in the group chosen for i (a launch reads / writes the buffers of ONE set: its records, planes and
+ * RGB are in three different groups); any_group[i] != 0 (may be NULL = none): buffer i goes wherever room is left.  At most
+ * four buffers may ask for a group of their own.  The decode engine uses it when MINIVIDEO_PLACED=1. */
+MVHP_EXPORT int  mvhp_placed_alloc_sets(int device, int sets, int count, const size_t *bytes, const uint8_t *any_group,
+                                        size_t arena_bytes, void **d_ptrs, void **arena, int *groups_of, int *groups_found);
 MVHP_EXPORT void mvhp_placed_free(void *arena);
 
 #ifdef __cplusplus

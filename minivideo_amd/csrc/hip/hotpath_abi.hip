@@ -558,9 +558,26 @@ int eng_recon(DevCtx *d, const mvhp_stream_params_t *p, const void *d_compact, s
     return MVHP_SUCCESS;
 }
 
+// the engine's batch buffers from one placed arena (MINIVIDEO_PLACED=1): records / planes / RGB of a batch in three groups of
+// the device's memory regions (placement.hip); the compact staging area goes wherever room is left
+void *eng_placed_alloc(DevCtx *d, int sets, const size_t bytes[4], void **ptrs)
+{
+    static const uint8_t any_group[4] = {1, 0, 0, 0};   // {compact, records, planes, RGB}
+    void *arena = nullptr;
+    int found = 0;
+    if (mvhp_placed_alloc_sets(d->c->device, sets, 4, bytes, any_group, 0, ptrs, &arena, nullptr, &found) != MVHP_SUCCESS) return nullptr;
+    return arena;
+}
+
+void eng_placed_free(DevCtx *d, void *arena)
+{
+    (void)d;
+    mvhp_placed_free(arena);
+}
+
 const mvengine::DeviceApi g_hip_api = {
     mvhp_device_count, mvhp_host_alloc, mvhp_host_free, eng_ctx_create, eng_ctx_destroy, eng_dev_alloc, eng_dev_free,
-    eng_dev_free_bytes, eng_h2d, eng_d2h, eng_recon,
+    eng_dev_free_bytes, eng_h2d, eng_d2h, eng_recon, eng_placed_alloc, eng_placed_free,
 };
 
 } // namespace

@@ -254,6 +254,149 @@ MVHP_EXPORT int mvhp_placed_alloc(int device, int count, const size_t *bytes, si
     return MVHP_SUCCESS;
 }
 
+// The same for a PIPELINE's batch buffers (the decode engine: three batches in flight per context): `sets` copies of `count`
+// buffers, out[s * count + i] = buffer i of set s.  Buffer i of every set lies in the group chosen for i -- what matters to a
+// launch is that ITS records, planes and RGB sit in three different groups, and every set is one launch's buffers; buffers with
+// any_group[i] != 0 (a staging area no kernel streams from at speed) go wherever room is left.  At most four buffers may ask
+// for a group of their own.  MVHP_FAILURE: not enough memory, or the arena does not show enough groups with room -- use
+// ordinary allocations.
+MVHP_EXPORT int mvhp_placed_alloc_sets(int device, int sets, int count, const size_t *bytes, const uint8_t *any_group,
+                                       size_t arena_bytes, void **out, void **arena, int *groups_of, int *groups_found)
+{
+    if (!out || !arena || !bytes || sets <= 0 || sets > 8 || count <= 0 || count > 8) return MVHP_FAILURE;
+    if (hipSetDevice(device) != hipSuccess) return MVHP_FAILURE;
+    size_t fr = 0, tot = 0, need = 0;
+    if (hipMemGetInfo(&fr, &tot) != hipSuccess) return MVHP_FAILURE;
+    std::vector<size_t> nblk((size_t)count);
+    std::vector<int> own;   // the buffers that want a group of their own
+    for (int i = 0; i < count; i++) {
+        if (bytes[i] == 0) return MVHP_FAILURE;
+        nblk[(size_t)i] = (bytes[i] + kBlock - 1) / kBlock;
+        need += nblk[(size_t)i] * kBlock * (size_t)sets;
+        if (!any_group || !any_group[i]) own.push_back(i);
+    }
+    if (own.size() > 4) return MVHP_FAILURE;
+    if (arena_bytes == 0) {
+        const size_t reserve = (size_t)24 << 30;
+        arena_bytes = fr > reserve ? std::min(fr - reserve, (size_t)200 << 30) : 0;
+    }
+    arena_bytes = arena_bytes / kBlock * kBlock;
+    if (arena_bytes < need) return MVHP_FAILURE;
+    void *base = nullptr;
+    if (hipMalloc(&base, arena_bytes) != hipSuccess) { (void)hipGetLastError(); return MVHP_FAILURE; }
+    const size_t nb = arena_bytes / kBlock;
+    auto at = [&](size_t blk, size_t off) { return (void *)((uint8_t *)base + blk * kBlock + off); };
+    Probe probe{device};
+    // groups of the 4-GB blocks, as in mvhp_placed_alloc: against one representative per group
+    std::vector<float> cal;
+    for (size_t b = 0; b < nb && cal.size() < 7; b += std::max<size_t>(1, nb / 7)) cal.push_back(probe(at(b, 0), at(b, kWindow)));
+    std::sort(cal.begin(), cal.end());
+    const float t_same = cal[cal.size() / 2];
+    std::vector<int> group(nb, 0);
+    std::vector<size_t> reps;
+    for (size_t b = 0; b < nb; b++) {
+        int best = -1;
+        float tbest = 0.f;
+        for (size_t g = 0; g < reps.size(); g++) {
+            const float t = reps[g] == b ? t_same : probe(at(reps[g], 0), at(b, 0));
+            if (t > tbest) { tbest = t; best = (int)g; }
+        }
+        if (best >= 0 && tbest >= 0.955f * t_same) group[b] = best;
+        else if (reps.size() < 6) { group[b] = (int)reps.size(); reps.push_back(b); }
+        else group[b] = best < 0 ? 0 : best;
+    }
+    if (probe.failed) { (void)hipFree(base); return MVHP_FAILURE; }
+    const int G = (int)reps.size();
+    // `sets` disjoint runs of `want` blocks inside group g (first fit); empty = no room
+    auto runs_in = [&](int g, size_t want, const std::vector<char> &taken_) {
+        std::vector<size_t> starts;
+        std::vector<char> t = taken_;
+        for (size_t s0 = 0; s0 + want <= nb && (int)starts.size() < sets; s0++) {
+            bool okrun = true;
+            for (size_t k = 0; k < want && okrun; k++) okrun = !t[s0 + k] && (g < 0 || group[s0 + k] == g);
+            if (!okrun) continue;
+            starts.push_back(s0);
+            for (size_t k = 0; k < want; k++) t[s0 + k] = 1;
+            s0 += want - 1;
+        }
+        if ((int)starts.size() < sets) starts.clear();
+        return starts;
+    };
+    std::vector<char> taken(nb, 0);
+    const int K = (int)own.size();
+    bool ok = G >= K;
+    std::vector<int> pick((size_t)K, -1), best_pick;
+    if (ok && K > 0) {
+        // which groups go together is MEASURED (labels alone misplaced a batch once in a dozen runs): pair times between the
+        // windows where buffer i would start in group g
+        std::vector<std::vector<long>> win((size_t)K, std::vector<long>((size_t)G, -1));
+        for (int a = 0; a < K; a++)
+            for (int g = 0; g < G; g++) {
+                const std::vector<size_t> r = runs_in(g, nblk[(size_t)own[(size_t)a]], taken);
+                if (!r.empty()) win[(size_t)a][(size_t)g] = (long)r[0];
+            }
+        std::vector<long> gw((size_t)G, -1);
+        for (int g = 0; g < G; g++)
+            for (int a = 0; a < K && gw[(size_t)g] < 0; a++) gw[(size_t)g] = win[(size_t)a][(size_t)g];
+        std::vector<std::vector<float>> pt((size_t)G, std::vector<float>((size_t)G, 0.f));
+        for (int x = 0; x < G; x++)
+            for (int y = x + 1; y < G; y++)
+                if (gw[(size_t)x] >= 0 && gw[(size_t)y] >= 0)
+                    pt[(size_t)x][(size_t)y] = pt[(size_t)y][(size_t)x] =
+                        std::min(probe(at((size_t)gw[(size_t)x], 0), at((size_t)gw[(size_t)y], 0)),
+                                 probe(at((size_t)gw[(size_t)x], kWindow), at((size_t)gw[(size_t)y], kWindow)));
+        if (probe.failed) { (void)hipFree(base); return MVHP_FAILURE; }
+        float best_score = 1e30f;
+        std::vector<char> used((size_t)G, 0);
+        auto rec = [&](auto &&self, int a, float score) -> void {
+            if (score >= best_score) return;
+            if (a == K) { best_score = score; best_pick = pick; return; }
+            for (int g = 0; g < G; g++) {
+                if (used[(size_t)g] || win[(size_t)a][(size_t)g] < 0) continue;
+                float add = 0.f;
+                for (int k = 0; k < a; k++) add += pt[(size_t)pick[(size_t)k]][(size_t)g];
+                used[(size_t)g] = 1;
+                pick[(size_t)a] = g;
+                self(self, a + 1, score + add);
+                used[(size_t)g] = 0;
+            }
+        };
+        rec(rec, 0, 0.f);
+        ok = !best_pick.empty();
+    }
+    if (ok) {
+        for (int a = 0; a < K && ok; a++) {
+            const int i = own[(size_t)a], g = best_pick[(size_t)a];
+            const std::vector<size_t> r = runs_in(g, nblk[(size_t)i], taken);
+            if (r.empty()) { ok = false; break; }   // (two buffers' runs competed for the same group: cannot happen with distinct groups)
+            for (int st = 0; st < sets; st++) {
+                for (size_t k = 0; k < nblk[(size_t)i]; k++) taken[r[(size_t)st] + k] = 1;
+                out[(size_t)st * (size_t)count + (size_t)i] = at(r[(size_t)st], 0);
+            }
+            if (groups_of) groups_of[i] = g;
+        }
+        for (int i = 0; i < count && ok; i++) {
+            if (!any_group || !any_group[i]) continue;
+            const std::vector<size_t> r = runs_in(-1, nblk[(size_t)i], taken);
+            if (r.empty()) { ok = false; break; }
+            for (int st = 0; st < sets; st++) {
+                for (size_t k = 0; k < nblk[(size_t)i]; k++) taken[r[(size_t)st] + k] = 1;
+                out[(size_t)st * (size_t)count + (size_t)i] = at(r[(size_t)st], 0);
+            }
+            if (groups_of) groups_of[i] = -1;
+        }
+    }
+    if (getenv("MVHP_PLACEMENT_TRACE")) {
+        fprintf(stderr, "placement (sets): arena %.0f GB, %d groups, groups per 4 GB:", arena_bytes / 1073741824.0, G);
+        for (size_t b = 0; b < nb; b++) fprintf(stderr, " %c", 'A' + group[b]);
+        fprintf(stderr, "; %s\n", ok ? "placed" : "NO ROOM");
+    }
+    if (!ok) { (void)hipFree(base); return MVHP_FAILURE; }
+    if (groups_found) *groups_found = G;
+    *arena = new Arena{device, base, arena_bytes};
+    return MVHP_SUCCESS;
+}
+
 MVHP_EXPORT void mvhp_placed_free(void *arena)
 {
     Arena *a = (Arena *)arena;

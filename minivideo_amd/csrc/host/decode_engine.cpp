@@ -169,6 +169,10 @@ struct Ctx {
     std::deque<int> to_launch, to_download;
     bool fail_next = false;
     bool launched_once = false;   // (over the engine's life: the code objects stay loaded)
+    void *arena = nullptr;        // MINIVIDEO_PLACED=1: the three batch buffers live in one placed arena ...
+    int arena_pictures = 0;       // ... sized for this many pictures per batch ...
+    mvhp_stream_params_t arena_params{};   // ... of this shape
+    bool arena_tried = false;
     size_t mem_budget = 0;   // bytes one batch may occupy on the device
 };
 
@@ -235,6 +239,8 @@ private:
     std::mutex alloc_mu_;
     double alloc_host_s_ = 0, alloc_dev_s_ = 0, first_launch_s_ = 0, first_picture_s_ = 0;
     uint64_t alloc_host_bytes_ = 0, alloc_dev_bytes_ = 0;
+    bool placed_ = false;    // MINIVIDEO_PLACED=1 / opts.reserved[0] & 1
+    int job_cap_ = 1;        // the largest batch the running call can form (per context)
 };
 
 Engine::~Engine()
@@ -242,6 +248,10 @@ Engine::~Engine()
     for (auto &c : all_in_) api_.host_free(c->buf.p);
     for (auto &c : all_out_) { api_.host_free(c->yuv.p); api_.host_free(c->rgb.p); }
     for (Ctx &c : ctx_) {
+        if (c.arena) {   // the buffers are pieces of the arena
+            api_.placed_free(c.dev, c.arena);
+            for (DevBuf &b : c.bufs) b = DevBuf();
+        }
         for (DevBuf &b : c.bufs) {
             if (b.compact) api_.dev_free(c.dev, b.compact);
             if (b.packed) api_.dev_free(c.dev, b.packed);
@@ -273,6 +283,7 @@ bool Engine::init(const mvhp_engine_opts_t *opts, std::string &err)
     if (host_threads_ > 256) host_threads_ = 256;
     if (opts_.batch_pictures <= 0) opts_.batch_pictures = env_int("MINIVIDEO_BATCH", 0);
     if (opts_.fail_context < 0) opts_.fail_context = env_int("MINIVIDEO_TEST_FAIL_CONTEXT", -1);
+    placed_ = (opts_.reserved[0] & 1) != 0 || env_int("MINIVIDEO_PLACED", 0) != 0;
     ctx_.resize((size_t)n_ctx);
     for (int k = 0; k < n_ctx; k++) {
         ctx_[k].device = (std::max(0, opts_.first_device) + k) % n_dev;
@@ -334,6 +345,8 @@ int Engine::batch_capacity(const mvhp_stream_params_t &p, int remaining) const
     for (const Ctx &c : ctx_) budget = std::min(budget, c.mem_budget);
     const int mem_cap = (int)std::min<size_t>(1 << 20, std::max<size_t>(1, budget / std::max<size_t>(1, per_pic)));
     cap = std::min(cap, mem_cap);
+    for (const Ctx &c : ctx_)
+        if (c.arena && c.arena_pictures > 0 && same_params(c.arena_params, p)) cap = std::min(cap, c.arena_pictures);
     const int share = (remaining + n_ctx - 1) / n_ctx;
     if (opts_.batch_pictures > 0) return std::max(1, std::min(cap, share));   // an explicit batch size is taken as given
     const int round = next_batch_id_ / n_ctx;                                   // batches each context has been given so far
@@ -344,6 +357,49 @@ int Engine::batch_capacity(const mvhp_stream_params_t &p, int remaining) const
 
 bool Engine::ensure_devbuf(Ctx &c, DevBuf &b, const Batch &bt, std::string &err)
 {
+    // MINIVIDEO_PLACED=1 (opt-in; for engines that live long: the arena is one allocation of up to 200 GB, seconds to get):
+    // the context's three batch buffers come from mvhp_placed_alloc_sets -- records, planes and RGB of a batch each in a group
+    // of the device's memory regions of its own, which is where the bench's kernel timings are taken (DESIGN 3 "Placement").
+    // Once, for the first batch shape the context sees, sized for the largest batch the job can form; a batch that does not fit
+    // (another shape, a larger explicit batch) uses ordinary allocations as before.
+    if (placed_ && api_.placed_alloc && !c.arena_tried) {
+        c.arena_tried = true;
+        const int n = std::max(bt.capacity, job_cap_);
+        const size_t bytes[4] = {(size_t)n * compact_slot_bytes(bt.params), (size_t)n * mvhp_packed_frame_bytes(&bt.params),
+                                 (size_t)n * mvhp_yuv_frame_bytes(&bt.params), (size_t)n * mvhp_rgb_frame_bytes(&bt.params)};
+        void *ptrs[12];
+        const double t0 = now_s();
+        c.arena = api_.placed_alloc(c.dev, 3, bytes, ptrs);
+        {
+            std::lock_guard<std::mutex> l(alloc_mu_);
+            alloc_dev_s_ += now_s() - t0;
+            if (c.arena) alloc_dev_bytes_ += 3 * (bytes[0] + bytes[1] + bytes[2] + bytes[3]);
+        }
+        if (c.arena) {
+            c.arena_pictures = n;
+            c.arena_params = bt.params;
+            for (int k = 0; k < 3; k++) {
+                DevBuf &d = c.bufs[k];
+                // (ordinary buffers from an earlier call of another shape are released; none is in use: the first batch)
+                if (d.compact) api_.dev_free(c.dev, d.compact);
+                if (d.packed) api_.dev_free(c.dev, d.packed);
+                if (d.yuv) api_.dev_free(c.dev, d.yuv);
+                if (d.rgb) api_.dev_free(c.dev, d.rgb);
+                d.compact = ptrs[k * 4 + 0]; d.compact_cap = bytes[0];
+                d.packed = ptrs[k * 4 + 1]; d.packed_cap = bytes[1];
+                d.yuv = (uint8_t *)ptrs[k * 4 + 2]; d.yuv_cap = bytes[2];
+                d.rgb = (uint8_t *)ptrs[k * 4 + 3]; d.rgb_cap = bytes[3];
+            }
+        }
+    }
+    if (c.arena) {
+        const size_t n = (size_t)bt.capacity;
+        if (n * compact_slot_bytes(bt.params) <= b.compact_cap && n * mvhp_packed_frame_bytes(&bt.params) <= b.packed_cap &&
+            n * mvhp_yuv_frame_bytes(&bt.params) <= b.yuv_cap && n * mvhp_rgb_frame_bytes(&bt.params) <= b.rgb_cap)
+            return true;
+        err = "batch of " + std::to_string(bt.capacity) + " pictures does not fit the placed arena";
+        return false;   // (batch_capacity() keeps batches inside the arena; another picture size in one call is refused)
+    }
     auto need = [&](void **ptr, size_t *cap, size_t bytes) {
         if (*cap >= bytes) return true;
         const double t0 = now_s();
@@ -865,6 +921,14 @@ int Engine::decode(const mvhp_stream &s, const int *order, int n_order, int want
         for (int i = 0; i < n_order; i++)
             if (mvhp_stream_params(&s, order[i], &p0) == MVHP_SUCCESS) { C = chunk_pictures(p0); break; }
         in_limit_ = (size_t)std::max(3, (host_threads_ + C - 1) / C + 1 + n_ctx);
+        {   // the largest batch this call can form on a context: what a placed arena is sized for
+            int cap = opts_.batch_pictures > 0 ? opts_.batch_pictures : ((n_order_ >= 4096 * n_ctx) ? 2048 : 1024);
+            const size_t per_pic = compact_slot_bytes(p0) + mvhp_packed_frame_bytes(&p0) + mvhp_yuv_frame_bytes(&p0) + mvhp_rgb_frame_bytes(&p0);
+            size_t budget = ctx_[0].mem_budget;
+            for (const Ctx &c : ctx_) budget = std::min(budget, c.mem_budget);
+            cap = std::min<int>(cap, (int)std::min<size_t>(1 << 20, std::max<size_t>(1, budget / std::max<size_t>(1, per_pic))));
+            job_cap_ = std::max(1, std::min(cap, (wanted_ + n_ctx - 1) / n_ctx));
+        }
         out_limit_ = (size_t)(2 * n_ctx + 2);
     }
     const int threads = std::min(host_threads_, std::max(1, wanted_));
@@ -937,6 +1001,7 @@ int Engine::decode(const mvhp_stream &s, const int *order, int n_order, int want
             st_.first_picture_s = first_picture_s_;
             st_.host_alloc_bytes = alloc_host_bytes_; st_.dev_alloc_bytes = alloc_dev_bytes_;
         }
+        for (const Ctx &c : ctx_) if (c.arena) st_.placed_buffers = 1;
         if (getenv("MINIVIDEO_ENGINE_TRACE")) {   // where the wall time went (developer aid)
             double wait = 0, wmax = 0, bmin = 1e30, bmax = 0;
             for (double w : worker_wait_) { wait += w; wmax = std::max(wmax, w); }

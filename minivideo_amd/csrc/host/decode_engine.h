@@ -39,6 +39,10 @@ struct DeviceApi {
     // compact pictures (`stride` bytes apart) -> packed records in d_packed (scratch) -> planes (+ RGB)
     int    (*recon)(DevCtx *c, const mvhp_stream_params_t *p, const void *d_compact, size_t stride, void *d_packed,
                     int n_pictures, uint8_t *d_yuv, uint8_t *d_rgb, float *ms, int *layout, int *waves, std::string &err);
+    // optional (may be NULL): `sets` x 4 batch buffers {compact, records, planes, RGB} inside one arena, records / planes / RGB
+    // each in a group of the device's memory regions of its own (mvhp_placed_alloc_sets); ptrs[s * 4 + i]; nullptr = failed
+    void  *(*placed_alloc)(DevCtx *c, int sets, const size_t bytes[4], void **ptrs);
+    void   (*placed_free)(DevCtx *c, void *arena);
 };
 
 class Engine;

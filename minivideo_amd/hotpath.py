@@ -265,7 +265,7 @@ SINK_T = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_char_p,
 class Engine:
     """mvhp_engine_t: host entropy threads -> H2D -> batched kernels -> D2H -> sink, over every context."""
 
-    def __init__(self, contexts=0, host_threads=0, batch_pictures=0, chunk_pictures=0, fail_context=-1, first_device=0):
+    def __init__(self, contexts=0, host_threads=0, batch_pictures=0, chunk_pictures=0, fail_context=-1, first_device=0, placed=False):
         self._L = L = lib()
         L.mvhp_engine_create.restype = C.c_int
         L.mvhp_engine_create.argtypes = [C.POINTER(EngineOpts), C.POINTER(C.c_void_p)]
@@ -275,6 +275,7 @@ class Engine:
         L.mvhp_engine_decode.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, SINK_T,
                                          C.c_void_p, C.POINTER(DecodeStats)]
         o = EngineOpts(contexts, host_threads, batch_pictures, chunk_pictures, fail_context, first_device)
+        o.reserved[0] = 1 if placed else 0   # bit 0: batch buffers from mvhp_placed_alloc_sets (same as MINIVIDEO_PLACED=1)
         h = C.c_void_p()
         if L.mvhp_engine_create(C.byref(o), C.byref(h)) != SUCCESS:
             raise MiniVideoError("mvhp_engine_create failed (no HIP device? there is no CPU reconstruction path)")

@@ -75,3 +75,54 @@ def test_probe_pair_times_two_windows():
         assert L.mvhp_probe_pair(0, None, pb.ptrs[1], 256 << 20, 2, C.byref(ms)) == 0
     finally:
         pb.close()
+
+
+def test_placed_sets_are_disjoint_and_a_group_per_buffer():
+    """mvhp_placed_alloc_sets: three sets of {staging, records, planes, RGB}; buffer i of every set in the group chosen for i"""
+    L = lib()
+    L.mvhp_placed_alloc_sets.restype = C.c_int
+    L.mvhp_placed_alloc_sets.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_uint8), C.c_size_t,
+                                         C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.mvhp_placed_free.argtypes = [C.c_void_p]
+    sizes = [1 * GB, 5 * GB, 2 * GB, 4 * GB + 1]
+    arr = (C.c_size_t * 4)(*sizes)
+    anyg = (C.c_uint8 * 4)(1, 0, 0, 0)
+    ptrs, arena, gof, gf = (C.c_void_p * 12)(), C.c_void_p(), (C.c_int * 4)(), C.c_int()
+    rc = L.mvhp_placed_alloc_sets(0, 3, 4, arr, anyg, 0, ptrs, C.byref(arena), gof, C.byref(gf))
+    if rc != 1:
+        pytest.skip("the arena shows fewer than three groups with room on this device (callers fall back to ordinary allocations)")
+    try:
+        spans = sorted((int(ptrs[s * 4 + i]), int(ptrs[s * 4 + i]) + sizes[i]) for s in range(3) for i in range(4))
+        assert all(spans[k][1] <= spans[k + 1][0] for k in range(11)), spans
+        assert gf.value >= 3 and gof[0] == -1 and len({gof[1], gof[2], gof[3]}) == 3
+    finally:
+        L.mvhp_placed_free(arena)
+    assert L.mvhp_placed_alloc_sets(0, 3, 4, arr, anyg, 8 * GB, ptrs, C.byref(arena), gof, C.byref(gf)) != 1   # too small
+
+
+def test_engine_on_a_placed_arena_matches_the_oracle():
+    """MINIVIDEO_PLACED=1 / Engine(placed=True): the context's three batch buffers are pieces of one placed arena"""
+    from minivideo_amd import Engine, gen
+    from minivideo_amd.hotpath import StreamParams
+    from tests.util import Stream
+    W, H, F = 20, 12, 150
+    stream, packed = gen.make_stream(W, H, F, seed=404, profile="high")
+    p = StreamParams(W, H, 0, 0, 0)
+    got = {}
+
+    def sink(seq, idr, rc, err, pr, yuv, rgb):
+        got[seq] = (rc, yuv.copy(), rgb.copy())
+        return 1 if rc == 1 else 0
+
+    eng = Engine(contexts=1, batch_pictures=32, placed=True)
+    with Stream(stream) as s:
+        rc, st = eng.decode(s.h, list(range(F)), want_rgb=True, sink=sink)
+        rc2, st2 = eng.decode(s.h, list(range(F - 1, -1, -1)), want_rgb=True)     # the arena is kept: nothing is allocated again
+    eng.close()
+    assert rc == 1 and st["pictures_ok"] == F and rc2 == 1 and st2["pictures_ok"] == F
+    if not st["placed_buffers"]:
+        pytest.skip("no placed arena on this device (too few groups / memory): the engine used ordinary allocations")
+    assert st2["placed_buffers"] == 1 and st2["dev_alloc_bytes"] == 0
+    for k in range(F):
+        ref_yuv, ref_rgb = loader.recon(p, packed[k], 1, want_rgb=True)
+        assert got[k][0] == 1 and np.array_equal(got[k][1], ref_yuv) and np.array_equal(got[k][2], ref_rgb), k

@@ -113,7 +113,8 @@ int stub_recon(DevCtx *, const mvhp_stream_params_t *p, const void *d_compact, s
 }
 
 const mvengine::DeviceApi g_stub = {stub_device_count, stub_host_alloc, stub_host_free, stub_ctx_create, stub_ctx_destroy,
-                                    stub_dev_alloc, stub_dev_free, stub_dev_free_bytes, stub_copy_n, stub_copy_n, stub_recon};
+                                    stub_dev_alloc, stub_dev_free, stub_dev_free_bytes, stub_copy_n, stub_copy_n, stub_recon,
+                                    nullptr, nullptr};   // (no placed arena on the stub device)
 
 struct Check {
     const mvhp_stream *s = nullptr;
