@@ -857,7 +857,12 @@ MVHP_MARK("p_i8_end");
 #define MVHP_ST_(ADDR, DATA, BASE, OFF) asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 offset:" #OFF MVHP_STORE_HINT "\n\ts_nop 1" : : "v"(ADDR), "v"(DATA), "s"(BASE) : "memory")
 #define MVHP_ST2(ADDR, DATA, BASE) asm volatile("s_nop 4\n\tglobal_store_dwordx2 %0, %1, %2" MVHP_STORE_HINT : : "v"(ADDR), "v"(DATA), "s"(BASE) : "memory")
                         MVHP_MARK("wo_planes");
-                        if (valid) {
+#if defined(MVHP_SPREAD_STORES)   // measurement build: the plane stores of a row pair behind its RGB stores instead of all sixteen up front
+                        const bool planes_first = !RGB;
+#else
+                        const bool planes_first = true;
+#endif
+                        if (valid && planes_first) {
                             MVHP_ST(pl, L0, gyuv, 0);            MVHP_ST(pl + pitch, L1, gyuv, 0);
                             MVHP_ST(pl + p4, L2, gyuv, 0);       MVHP_ST(pl + p4 + pitch, L3, gyuv, 0);
                             MVHP_ST(pl + 2 * p4, L4, gyuv, 0);   MVHP_ST(pl + 2 * p4 + pitch, L5, gyuv, 0);
@@ -887,10 +892,21 @@ MVHP_MARK("p_i8_end");
                                     asm volatile("" : : "v"(a0), "v"(a1), "v"(a2), "v"(c0), "v"(c1), "v"(c2));         \
                                 }                                                                                      \
                             }
-                            MVHP_RGB_OUT(L0, L1, cb0, cr0, 0u)
-                            MVHP_RGB_OUT(L2, L3, cb1, cr1, 1u)
-                            MVHP_RGB_OUT(L4, L5, cb2, cr2, 2u)
-                            MVHP_RGB_OUT(L6, L7, cb3, cr3, 3u)
+#if defined(MVHP_SPREAD_STORES)
+#define MVHP_PLANES_OUT(LA, LB, CBV, CRV, I)                                                                          \
+                            if (valid) {                                                                               \
+                                const v2i cbq = {(int)(CBV).x, (int)(CBV).y}, crq = {(int)(CRV).x, (int)(CRV).y};      \
+                                MVHP_ST(pl + (I) * p4, LA, gyuv, 0); MVHP_ST(pl + (I) * p4 + pitch, LB, gyuv, 0);      \
+                                MVHP_ST2(pcb + (I) * c2, cbq, gyuv); MVHP_ST2(pcr + (I) * c2, crq, gyuv);              \
+                            }
+#else
+#define MVHP_PLANES_OUT(LA, LB, CBV, CRV, I)
+#endif
+                            MVHP_RGB_OUT(L0, L1, cb0, cr0, 0u) MVHP_PLANES_OUT(L0, L1, cb0, cr0, 0u)
+                            MVHP_RGB_OUT(L2, L3, cb1, cr1, 1u) MVHP_PLANES_OUT(L2, L3, cb1, cr1, 1u)
+                            MVHP_RGB_OUT(L4, L5, cb2, cr2, 2u) MVHP_PLANES_OUT(L4, L5, cb2, cr2, 2u)
+                            MVHP_RGB_OUT(L6, L7, cb3, cr3, 3u) MVHP_PLANES_OUT(L6, L7, cb3, cr3, 3u)
+#undef MVHP_PLANES_OUT
 #undef MVHP_RGB_OUT
                         }
 #undef MVHP_ST

@@ -6,6 +6,7 @@ import time
 import numpy as np
 
 sys.path.insert(0, '.')
+n_spec = 0
 from minivideo_amd import HotPath
 from minivideo_amd.synth import synth_packed
 from oracle import loader
@@ -31,7 +32,23 @@ while time.time() - t0 < budget:
         kw["illegal_modes"] = True
     if lo <= 36 <= hi and rng.random() < 0.5:
         kw["allow_qp36_i16"] = True
-    params, rec = synth_packed(W, H, n, seed=int(rng.integers(0, 1 << 30)), **kw)
+    if rng.random() < 0.15:   # round 3: MVHP_STREAM_SPEC streams -- several slices, I_PCM, scaling lists (generator -> front end -> records)
+        from minivideo_amd import gen
+        from tests.util import Stream
+        sprof = ["baseline", "main", "high", "high_cavlc"][int(rng.integers(0, 4))]
+        W, H, n = min(W, 24), min(H, 16), min(n, 4)
+        stream, packed, _ = gen.make_stream_ex(W, H, n, seed=int(rng.integers(0, 1 << 30)), profile=sprof, slices=int(rng.integers(1, 6)),
+                                               pcm_permille=int(rng.choice([0, 40, 300])), scaling=int(rng.integers(0, 4)) if sprof.startswith("high") else 0,
+                                               qp_range=(lo, hi))
+        with Stream(stream, spec=True) as st:
+            params = st.params(0)
+            rec = np.stack([st.packed(k)[1] for k in range(n)])
+        if not np.array_equal(rec.reshape(packed.shape), packed):
+            print("FRONT END != GENERATOR", W, H, n, sprof, flush=True)
+            sys.exit(1)
+        n_spec = globals().get("n_spec", 0) + 1
+    else:
+        params, rec = synth_packed(W, H, n, seed=int(rng.integers(0, 1 << 30)), **kw)
     h.set_layout(layout); h.set_waves_per_picture(waves)
     g, gr = h.recon_host(params, rec, n, want_rgb=rgb)
     o, orr = loader.recon(params, rec, n, want_rgb=rgb)
@@ -42,4 +59,4 @@ while time.time() - t0 < budget:
     if time.time() - t_print > 30:   # progress line (a silent GPU job is taken to be hung)
         t_print = time.time()
         print("... %d cases, %d macroblocks, %.0f s" % (n_cases, n_mb, time.time() - t0), flush=True)
-print("soak ok: %d cases, %d macroblocks, %.0f s" % (n_cases, n_mb, time.time() - t0))
+print("soak ok: %d cases (%d of them spec-mode streams), %d macroblocks, %.0f s" % (n_cases, globals().get("n_spec", 0), n_mb, time.time() - t0))
