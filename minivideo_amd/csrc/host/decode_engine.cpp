@@ -113,6 +113,7 @@ struct DevBuf {
     uint8_t *yuv = nullptr, *rgb = nullptr;
     size_t compact_cap = 0, packed_cap = 0, yuv_cap = 0, rgb_cap = 0;
     bool busy = false;
+    bool arena_piece = false;   // the four buffers are pieces of the context's placed arena: never freed one by one
 };
 
 // slot size of a compact picture: the format's upper bound, 16-byte aligned
@@ -248,9 +249,9 @@ Engine::~Engine()
     for (auto &c : all_in_) api_.host_free(c->buf.p);
     for (auto &c : all_out_) { api_.host_free(c->yuv.p); api_.host_free(c->rgb.p); }
     for (Ctx &c : ctx_) {
-        if (c.arena) {   // the buffers are pieces of the arena
+        if (c.arena) {   // pieces of the arena go with it; a buffer that left the arena is freed below like any other
+            for (DevBuf &b : c.bufs) if (b.arena_piece) b = DevBuf();
             api_.placed_free(c.dev, c.arena);
-            for (DevBuf &b : c.bufs) b = DevBuf();
         }
         for (DevBuf &b : c.bufs) {
             if (b.compact) api_.dev_free(c.dev, b.compact);
@@ -389,16 +390,20 @@ bool Engine::ensure_devbuf(Ctx &c, DevBuf &b, const Batch &bt, std::string &err)
                 d.packed = ptrs[k * 4 + 1]; d.packed_cap = bytes[1];
                 d.yuv = (uint8_t *)ptrs[k * 4 + 2]; d.yuv_cap = bytes[2];
                 d.rgb = (uint8_t *)ptrs[k * 4 + 3]; d.rgb_cap = bytes[3];
+                d.arena_piece = true;
             }
         }
     }
-    if (c.arena) {
+    if (b.arena_piece) {
         const size_t n = (size_t)bt.capacity;
         if (n * compact_slot_bytes(bt.params) <= b.compact_cap && n * mvhp_packed_frame_bytes(&bt.params) <= b.packed_cap &&
             n * mvhp_yuv_frame_bytes(&bt.params) <= b.yuv_cap && n * mvhp_rgb_frame_bytes(&bt.params) <= b.rgb_cap)
             return true;
-        err = "batch of " + std::to_string(bt.capacity) + " pictures does not fit the placed arena";
-        return false;   // (batch_capacity() keeps batches inside the arena; another picture size in one call is refused)
+        // a batch the arena was not sized for (another picture size, a later and longer job): this batch buffer leaves the
+        // arena for ordinary allocations -- its pieces stay where they are until the engine goes (batch_capacity() keeps
+        // batches of the arena's own shape inside it)
+        b = DevBuf();
+        b.busy = true;
     }
     auto need = [&](void **ptr, size_t *cap, size_t bytes) {
         if (*cap >= bytes) return true;

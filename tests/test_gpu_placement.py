@@ -126,3 +126,26 @@ def test_engine_on_a_placed_arena_matches_the_oracle():
     for k in range(F):
         ref_yuv, ref_rgb = loader.recon(p, packed[k], 1, want_rgb=True)
         assert got[k][0] == 1 and np.array_equal(got[k][1], ref_yuv) and np.array_equal(got[k][2], ref_rgb), k
+
+
+def test_engine_leaves_the_arena_for_a_shape_it_was_not_sized_for():
+    """an arena sized for the first job's pictures; a later job of larger pictures runs on ordinary allocations, bit-exact"""
+    from minivideo_amd import Engine, gen
+    from minivideo_amd.hotpath import StreamParams
+    from tests.util import Stream
+    eng = Engine(contexts=1, batch_pictures=8, placed=True)
+    for (W, H, F, seed) in ((6, 4, 20, 1), (30, 17, 20, 2)):
+        stream, packed = gen.make_stream(W, H, F, seed=seed, profile="baseline")
+        p = StreamParams(W, H, 0, 0, 0)
+        got = {}
+
+        def sink(seq, idr, rc, err, pr, yuv, rgb):
+            got[seq] = (rc, yuv.copy())
+            return 1 if rc == 1 else 0
+
+        with Stream(stream) as s:
+            rc, st = eng.decode(s.h, list(range(F)), want_rgb=True, sink=sink)
+        assert rc == 1 and st["pictures_ok"] == F, st
+        for k in range(F):
+            assert np.array_equal(got[k][1], loader.recon(p, packed[k], 1)[0]), (W, k)
+    eng.close()
