@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Measurement: the launch on buffers from mvhp_placed_alloc() against ordinary allocations, one process.
-usage (GPU box, repo root): python tools/placed_test.py [--profile baseline|high] [--mbs 120x68] [--frames 2048]"""
+usage (GPU box, repo root): python tools/placed_check.py [--profile baseline|high] [--mbs 120x68] [--frames 2048]"""
 import argparse
 import ctypes as C
 import os
