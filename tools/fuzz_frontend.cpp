@@ -1,7 +1,8 @@
 // tools/fuzz_frontend.cpp -- sanitizer harness for the host front end (CPU only):
 //   g++ -O1 -g -fsanitize=address,undefined -std=c++17 -Iinclude -Iminivideo_amd/csrc/host \
 //       tools/fuzz_frontend.cpp minivideo_amd/csrc/host/{h264_frontend,h264_cabac,stream_abi,mp4_demux}.cpp -o /tmp/fuzz_frontend
-//   /tmp/fuzz_frontend stream.264|clip.mp4 [iterations]      (a .mp4/.mov name goes through mvhp_stream_open_mp4)
+//   /tmp/fuzz_frontend stream.264|clip.mp4 [iterations] [spec]   (a .mp4/.mov name goes through mvhp_stream_open_mp4; `spec` opens
+//   the stream with MVHP_STREAM_SPEC)
 // Mutates the stream (bit flips, byte splats, truncations) and parses every picture; any memory error aborts.
 #include <stdio.h>
 #include <stdlib.h>
@@ -33,6 +34,7 @@ int main(int argc, char **argv)
     const size_t nl = strlen(argv[1]);
     const bool is_mp4 = nl > 4 && (!strcmp(argv[1] + nl - 4, ".mp4") || !strcmp(argv[1] + nl - 4, ".mov"));
     const int iters = argc > 2 ? atoi(argv[2]) : 2000;
+    const bool spec = argc > 3 && !strcmp(argv[3], "spec");   // MVHP_STREAM_SPEC: several slices, scaling lists, I_PCM are parsed
     long ok = 0, bad = 0;
     for (int it = 0; it < iters; it++) {
         std::vector<uint8_t> d = base;
@@ -46,13 +48,19 @@ int main(int argc, char **argv)
             else { d.resize(pos + 1); d.insert(d.end(), 64, 0); break; }
         }
         mvhp_stream_t *s = nullptr;
-        if ((is_mp4 ? mvhp_stream_open_mp4(d.data(), d.size(), &s) : mvhp_stream_open(d.data(), d.size(), &s)) != MVHP_SUCCESS) continue;
+        if ((is_mp4 ? mvhp_stream_open_mp4(d.data(), d.size(), &s)
+                    : spec ? mvhp_stream_open_ex(d.data(), d.size(), MVHP_STREAM_SPEC, &s) : mvhp_stream_open(d.data(), d.size(), &s)) != MVHP_SUCCESS) continue;
         const int cnt = mvhp_stream_idr_count(s);
         for (int k = 0; k < cnt; k++) {
             mvhp_stream_params_t p;
             if (mvhp_stream_params(s, k, &p) != MVHP_SUCCESS) continue;
             std::vector<uint8_t> packed((size_t)p.width_mbs * p.height_mbs * MVHP_MB_BYTES);
             if (mvhp_stream_decode_packed(s, k, packed.data(), packed.size()) == MVHP_SUCCESS) ok++; else bad++;
+            // the transfer format too (its own writer: offsets table, entry lists, dense fallback, I_PCM records)
+            std::vector<uint8_t> compact((size_t)p.width_mbs * p.height_mbs * MVHP_COMPACT_MB_BYTES_MAX + MVHP_COMPACT_SLACK_BYTES);
+            size_t used = 0;
+            (void)mvhp_stream_decode_compact(s, k, compact.data(), compact.size(), &used);
+            if (used > compact.size()) { fprintf(stderr, "compact picture overran its buffer\n"); return 1; }
         }
         mvhp_stream_close(s);
     }
