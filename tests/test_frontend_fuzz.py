@@ -83,5 +83,5 @@ def test_spec_mode_bit_flips_never_crash(profile, slices, pcm, scaling):
                     not_pcm = rec[:, 0] != 3
                     assert rec[not_pcm, 12:28].max(initial=0) <= 8
                 rc2, used, buf = decode_compact(s, k)
-                assert rc2 in (1, 0, -1) and used <= buf.size
+                assert rc2 in (1, 0, -1) and (buf is None or used <= buf.size)
     assert seen[1] > 0 and seen[0] + seen[-1] > 0
