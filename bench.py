@@ -397,9 +397,11 @@ def cli_cold(args, params, stream, n_distinct, rec):
             else:
                 ok = False
         stats = [l for l in r.stderr.splitlines() if l.startswith("[minivideo] decode:")]
+        call = [l for l in r.stderr.splitlines() if l.startswith("[minivideo] decode call:") or l.startswith("[minivideo] parse call:")]
         return {"what": "mini_thumbnailer -f yuv420 -n %d, a fresh process: stream file on tmpfs -> .yuv files on tmpfs" % n,
                 "value": n * params.mbs / wall, "unit": "macroblocks/s", "pictures": n, "wall_s": wall,
-                "files_equal_oracle": ok, "library_stats": stats[-1] if stats else None}
+                "files_equal_oracle": ok, "library_stats": stats[-1] if stats else None,
+                "library_calls": call or None}
     finally:
         shutil.rmtree(d, ignore_errors=True)
 

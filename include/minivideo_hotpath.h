@@ -306,7 +306,10 @@ typedef struct mvhp_decode_stats {
 
 /* Called on the calling thread, once per picture, in the order of `order`.  rc = MVHP_SUCCESS: yuv (and rgb when
  * asked for) point into page-locked memory valid during the call.  Otherwise yuv = rgb = NULL and err says why.
- * Return 1: picture accepted (counts towards `wanted`); 0: not accepted (counts as a failure); -1: stop decoding. */
+ * Return 1: picture accepted (counts towards `wanted`); 0: not accepted (counts as a failure); -1: stop decoding;
+ * 2: accepted AND kept -- yuv / rgb stay valid after the call returns, until mvhp_engine_release_picture(e, seq), which any
+ * thread may call (a pool of file writers: minivideo_decode).  Kept pictures occupy the engine's output chunks, so keep few
+ * (the pipeline waits for a free chunk); mvhp_engine_decode does not return before the last kept picture has been released. */
 typedef int (*mvhp_picture_sink_t)(void *user, int seq, int idr, int rc, const char *err,
                                    const mvhp_stream_params_t *p, const uint8_t *yuv, const uint8_t *rgb);
 
@@ -322,6 +325,8 @@ MVHP_EXPORT void mvhp_engine_destroy(mvhp_engine_t *e);
  * were accepted, or when the list ended after at least one. */
 MVHP_EXPORT int  mvhp_engine_decode(mvhp_engine_t *e, const mvhp_stream_t *s, const int *order, int n_order, int wanted,
                                     int want_rgb, mvhp_picture_sink_t sink, void *user, mvhp_decode_stats_t *stats);
+/* Gives back a picture the sink kept (verdict 2) during the running mvhp_engine_decode call; anything else is ignored. */
+MVHP_EXPORT void mvhp_engine_release_picture(mvhp_engine_t *e, int seq);
 
 /* ---- memory placement (MI355X: device memory alternates, in regions of tens of GB, between two halves of the memory
  * system; DESIGN.md 3 "Placement") ---- */

@@ -15,10 +15,18 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <deque>
 #include <memory>
+#include <mutex>
+#include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
+#include "decode_engine.h"
 #include "export.h"
 #include "h264_frontend.h"
 #include "minivideo.h"
@@ -115,19 +123,57 @@ void free_map(BitstreamMap_t **pm)
     *pm = NULL;
 }
 
-bool read_whole_file(MediaFile_t *m, std::vector<uint8_t> &buf)
+double wall_s()
 {
-    if (!m->file_pointer || m->file_size <= 0) return false;
-    buf.resize((size_t)m->file_size);
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// The whole file in memory.  (Not mapped: a file that shrinks under a mapping kills the process; a short read is an error
+// return.)  minivideo_parse leaves the bytes of the file it parsed last in a one-entry cache, so that the minivideo_decode
+// that follows does not read 200 MB a second time (0.06 s of a 1.2-s mini_thumbnailer run); minivideo_close drops it.
+struct FileBytes {
+    std::unique_ptr<uint8_t[]> p;   // (not a vector: no zero fill of what fread overwrites)
+    size_t n = 0;
+    const uint8_t *data() const { return p.get(); }
+    size_t size() const { return n; }
+};
+
+std::mutex g_last_parsed_mu;
+const MediaFile_t *g_last_parsed_owner = nullptr;
+std::shared_ptr<FileBytes> g_last_parsed;
+
+std::shared_ptr<FileBytes> read_whole_file(MediaFile_t *m)
+{
+    if (!m->file_pointer || m->file_size <= 0) return nullptr;
+    auto buf = std::make_shared<FileBytes>();
+    buf->n = (size_t)m->file_size;
+    buf->p.reset(new (std::nothrow) uint8_t[buf->n]);
+    if (!buf->p) return nullptr;
     rewind(m->file_pointer);
-    const size_t n = fread(buf.data(), 1, buf.size(), m->file_pointer);
+    const size_t got = fread(buf->p.get(), 1, buf->n, m->file_pointer);
     rewind(m->file_pointer);
-    return n == buf.size();
+    return got == buf->n ? buf : nullptr;
+}
+
+void remember_parsed(const MediaFile_t *m, std::shared_ptr<FileBytes> buf)
+{
+    std::lock_guard<std::mutex> l(g_last_parsed_mu);
+    g_last_parsed_owner = m;
+    g_last_parsed = std::move(buf);
+}
+
+std::shared_ptr<FileBytes> take_parsed(const MediaFile_t *m, bool keep)
+{
+    std::lock_guard<std::mutex> l(g_last_parsed_mu);
+    if (g_last_parsed_owner != m) return nullptr;
+    std::shared_ptr<FileBytes> r = g_last_parsed;
+    if (!keep) { g_last_parsed_owner = nullptr; g_last_parsed.reset(); }
+    return r;
 }
 
 // ---- MP4: public sample map as convertTrack builds it (demuxer/mp4/mp4.c:150-500): the avcC parameter sets first,
 //      then every sample of the video track, sync samples marked ----
-int parse_mp4_track(MediaFile_t *m, const std::vector<uint8_t> &buf)
+int parse_mp4_track(MediaFile_t *m, const FileBytes &buf)
 {
     mp4::VideoTrack trk;
     std::string err;
@@ -212,13 +258,74 @@ struct ExportSink {
     const char *ext = "yuv";
     bool want_rgb = false;
     int picture_number = 1;
-    int exported = 0, errors = 0;
+    int exported = 0, errors = 0;   // exported: pictures named so far (the _k of the file name)
     bool aborted = false;
+
+    // File writers (round 3): one picture's write to the page cache is a 3-6 MB copy, 0.5 ms -- on the calling thread that
+    // capped minivideo_decode at 2000 pictures/s while the pipeline delivers 3300.  The sink keeps the picture (verdict 2),
+    // a small pool writes it and gives it back.  MINIVIDEO_WRITERS=0: write on the calling thread as before.
+    struct Job { int seq; std::string name; int W, H; const uint8_t *yuv, *rgb; };
+    mvhp_engine_t *eng = nullptr;
+    std::vector<std::thread> pool;
+    std::mutex mu;
+    std::condition_variable cv_job, cv_room;
+    std::deque<Job> jobs;
+    size_t max_jobs = 8;            // pictures queued or being written: bounds what is kept out of the engine's chunks
+    size_t in_flight = 0;
+    int n_writers = 0;
+    bool closing = false;
+    std::atomic<int> written{0}, write_errors{0};
+
+    int write_one(const std::string &name, int W, int H, const uint8_t *yuv, const uint8_t *rgb) const
+    {
+        if (fmt == PICTURE_PNG) return mvexport::write_png(name, rgb, W, H);
+        if (fmt == PICTURE_BMP) return mvexport::write_bmp(name, rgb, W, H);
+        if (fmt == PICTURE_TGA) return mvexport::write_tga(name, rgb, W, H);
+        if (fmt == PICTURE_YUV444) return mvexport::write_yuv444(name, yuv, W, H);
+        return mvexport::write_yuv420(name, yuv, W, H);
+    }
+    void start(int n, mvhp_engine_t *e)
+    {
+        eng = e;
+        n_writers = n;
+        max_jobs = (size_t)n + 4;
+        for (int i = 0; i < n; i++) pool.emplace_back([this] { writer(); });
+    }
+    void finish()
+    {
+        {
+            std::lock_guard<std::mutex> l(mu);
+            closing = true;
+        }
+        cv_job.notify_all();
+        for (auto &t : pool) t.join();
+        pool.clear();
+    }
+    void writer()
+    {
+        for (;;) {
+            Job j;
+            {
+                std::unique_lock<std::mutex> l(mu);
+                cv_job.wait(l, [&] { return closing || !jobs.empty(); });
+                if (jobs.empty()) return;
+                j = std::move(jobs.front());
+                jobs.pop_front();
+            }
+            if (write_one(j.name, j.W, j.H, j.yuv, j.rgb)) written++;
+            else { log_err("Unable to write '%s'", j.name.c_str()); write_errors++; }
+            mvhp_engine_release_picture(eng, j.seq);
+            {
+                std::lock_guard<std::mutex> l(mu);
+                in_flight--;
+            }
+            cv_room.notify_one();
+        }
+    }
 
     static int call(void *user, int seq, int idr, int rc, const char *err, const mvhp_stream_params_t *p, const uint8_t *yuv,
                     const uint8_t *rgb)
     {
-        (void)seq;
         ExportSink &x = *static_cast<ExportSink *>(user);
         if (rc != MVHP_SUCCESS) {
             log_err("IDR %d: %s", idr, err ? err : "failed");
@@ -232,18 +339,26 @@ struct ExportSink {
         name += ".";
         name += x.ext;
         const int W = (int)p->width_mbs * 16, H = (int)p->height_mbs * 16;
-        int ok = 0;
-        if (x.fmt == PICTURE_PNG) ok = mvexport::write_png(name, rgb, W, H);
-        else if (x.fmt == PICTURE_BMP) ok = mvexport::write_bmp(name, rgb, W, H);
-        else if (x.fmt == PICTURE_TGA) ok = mvexport::write_tga(name, rgb, W, H);
-        else if (x.fmt == PICTURE_YUV444) ok = mvexport::write_yuv444(name, yuv, W, H);
-        else ok = mvexport::write_yuv420(name, yuv, W, H);
-        if (!ok) {
+        if (!x.pool.empty()) {
+            // a write that fails later is reported and counted, but no further picture is decoded in its place (the
+            // synchronous path below does that; so does the reference, whose write errors are as rare as a full disk)
+            {
+                std::unique_lock<std::mutex> l(x.mu);
+                x.cv_room.wait(l, [&] { return x.in_flight < x.max_jobs; });
+                x.in_flight++;
+                x.jobs.push_back(Job{seq, std::move(name), W, H, yuv, rgb});
+            }
+            x.cv_job.notify_one();
+            x.exported++;
+            return 2;
+        }
+        if (!x.write_one(name, W, H, yuv, rgb)) {
             log_err("Unable to write '%s'", name.c_str());
             x.errors++;
             return 0;
         }
         x.exported++;
+        x.written++;
         return 1;
     }
 };
@@ -309,8 +424,12 @@ minivideo_EXPORT int minivideo_parse(MediaFile_t *m, const bool extract_audio, c
                 getContainerString(m->container, false));
         return FAILURE;
     }
-    std::vector<uint8_t> buf;
-    if (!read_whole_file(m, buf)) { log_err("Unable to read the media file"); return FAILURE; }
+    const double t_call = wall_s();
+    std::shared_ptr<FileBytes> file = read_whole_file(m);
+    if (!file) { log_err("Unable to read the media file"); return FAILURE; }
+    const FileBytes &buf = *file;
+    remember_parsed(m, file);
+    const double t_read = wall_s();
     if (m->container == CONTAINER_MP4) return parse_mp4_track(m, buf);
     std::vector<h264::EsSample> samples;
     const bool spec = getenv("MINIVIDEO_SPEC") && atoi(getenv("MINIVIDEO_SPEC")) != 0;   // opt-in, SURVEY 8f row f4
@@ -347,6 +466,8 @@ minivideo_EXPORT int minivideo_parse(MediaFile_t *m, const bool extract_audio, c
     map->frame_count = map->frame_count_idr;
     m->tracks_video[0] = map;
     m->tracks_video_count = 1;
+    if (getenv("MINIVIDEO_STATS"))
+        fprintf(stderr, "[minivideo] parse call: reading the file %.3f s, indexing + sample map %.3f s\n", t_read - t_call, wall_s() - t_read);
     return SUCCESS;
 }
 
@@ -361,8 +482,25 @@ minivideo_EXPORT int minivideo_decode(MediaFile_t *m, const char *output_directo
     if (!map || map->stream_type != stream_VIDEO) { log_err("No video track to decode"); return FAILURE; }
     if (map->stream_codec != CODEC_H264) { log_err("Unable to decode given file format: no decoder available!"); return FAILURE; }
 
-    std::vector<uint8_t> buf;
-    if (!read_whole_file(m, buf)) { log_err("Unable to read the media file"); return FAILURE; }
+    // The engine (HIP runtime, one context per device, its thread pools: 0.2-0.5 s in a fresh process) comes up on a thread
+    // of its own while this one reads and indexes the file.
+    const double t_call = wall_s();
+    struct EngineStart {
+        mvhp_engine_t *eng = nullptr;
+        int rc = MVHP_FAILURE;
+        double seconds = 0;
+        std::thread th;
+        bool joined = false;
+        void join() { if (!joined) { th.join(); joined = true; } }
+        ~EngineStart() { join(); if (eng) mvhp_engine_destroy(eng); }
+    } es;
+    es.th = std::thread([&es] { const double t = wall_s(); es.rc = mvhp_engine_create(nullptr, &es.eng); es.seconds = wall_s() - t; });
+
+    std::shared_ptr<FileBytes> file = take_parsed(m, true);   // (a second minivideo_decode of the same file finds it again)
+    if (!file) file = read_whole_file(m);
+    if (!file) { log_err("Unable to read the media file"); return FAILURE; }
+    const FileBytes &buf = *file;
+    const double t_read = wall_s();
     mvhp_stream s;
     s.data = buf.data();
     s.size = buf.size();
@@ -389,20 +527,34 @@ minivideo_EXPORT int minivideo_decode(MediaFile_t *m, const char *output_directo
     else if (fmt == PICTURE_TGA) ext = "tga";
     const bool want_rgb = (fmt == PICTURE_PNG || fmt == PICTURE_BMP || fmt == PICTURE_TGA);
 
-    mvhp_engine_t *eng = nullptr;
-    if (mvhp_engine_create(nullptr, &eng) != MVHP_SUCCESS) return FAILURE;   // (the reason has been printed)
+    const double t_indexed = wall_s();
+    es.join();
+    if (es.rc != MVHP_SUCCESS) return FAILURE;   // (the reason has been printed)
+    mvhp_engine_t *eng = es.eng;
+    const double t_engine = wall_s();
     ExportSink sink;
     sink.m = m;
     sink.fmt = fmt;
     sink.ext = ext;
     sink.want_rgb = want_rgb;
     sink.picture_number = picture_number;
+    {   // file writers: two per sixteen cores keep up with the pipeline on the raw formats (0.5 ms of copying per picture);
+        // the entropy threads need the rest.  PNG (filter + stored deflate + two checksums per picture) gets twice as many.
+        const int cores = mvengine::effective_cores();
+        int writers = (fmt == PICTURE_PNG) ? std::min(8, std::max(1, cores / 4)) : std::min(4, std::max(1, cores / 8));
+        if (const char *e = getenv("MINIVIDEO_WRITERS")) writers = std::max(0, std::min(16, atoi(e)));
+        if (wanted < 4) writers = 0;
+        if (writers > 0) sink.start(writers, eng);
+    }
     mvhp_decode_stats_t st;
     // decodes in order until `wanted` pictures have been written (h264.c:173-179) or 64 errors in a row (h264.c:181-187)
     // RGB formats are written from the RGB picture alone: the planes stay on the device
     (void)mvhp_engine_decode(eng, &s, order.data(), (int)order.size(), wanted, want_rgb ? MVHP_OUT_RGB_ONLY : 0, ExportSink::call, &sink, &st);
-    mvhp_engine_destroy(eng);
-    if (getenv("MINIVIDEO_STATS"))
+    sink.finish();   // (every kept picture is back: mvhp_engine_decode waits for that)
+    if (getenv("MINIVIDEO_STATS")) {
+        fprintf(stderr, "[minivideo] decode call: reading the file %.3f s, indexing %.3f s, engine up after %.3f s (its thread took "
+                        "%.3f s), decode %.3f s, %d file writers\n", t_read - t_call, t_indexed - t_read, t_engine - t_call, es.seconds,
+                wall_s() - t_engine, (int)sink.n_writers);
         fprintf(stderr, "[minivideo] decode: %u pictures entropy-decoded, %u written, %u failed, %u launches (largest %u pictures), "
                         "%u contexts, %u host threads, %.3f s (first picture after %.3f s; page-locking %.3f s for %.2f GB, device "
                         "allocations %.3f s for %.2f GB, first launches %.3f s; entropy threads busy %.3f s, H2D %.3f s, kernels %.3f s, "
@@ -410,8 +562,9 @@ minivideo_EXPORT int minivideo_decode(MediaFile_t *m, const char *output_directo
                 st.max_batch_pictures, st.contexts, st.host_threads, st.wall_s, st.first_picture_s, st.host_alloc_s,
                 st.host_alloc_bytes / 1e9, st.dev_alloc_s, st.dev_alloc_bytes / 1e9, st.first_launch_s, st.entropy_busy_s, st.h2d_s,
                 st.kernel_s, st.d2h_s, st.sink_s);
+    }
     if (sink.aborted) return FAILURE;
-    return sink.exported > 0 ? SUCCESS : FAILURE;   // all wanted pictures, or the stream ended after the last good IDR
+    return sink.written.load() > 0 ? SUCCESS : FAILURE;   // all wanted pictures, or the stream ended after the last good IDR
 }
 
 minivideo_EXPORT int minivideo_extract(MediaFile_t *m, const char *output_directory, const bool extract_audio,
@@ -427,6 +580,7 @@ minivideo_EXPORT int minivideo_close(MediaFile_t **pm)
     int retcode = SUCCESS;
     if (pm && *pm) {
         MediaFile_t *m = *pm;
+        (void)take_parsed(m, false);
         if (m->file_pointer && fclose(m->file_pointer) != 0) retcode = FAILURE;
         for (int i = 0; i < 16; i++) { free_map(&m->tracks_audio[i]); free_map(&m->tracks_video[i]); free_map(&m->tracks_subt[i]); }
         free(m);

@@ -47,6 +47,8 @@ int env_int(const char *name, int dflt)
     return atoi(e);
 }
 
+} // namespace
+
 // Host cores this process may actually use: the hardware thread count, cut down to the CPU-time quota of the
 // container (cgroup v2 cpu.max / v1 cfs quota) -- a box of 256 hardware threads often grants 16 CPUs per GPU, and
 // 256 entropy threads sharing 16 CPUs only thrash.
@@ -66,6 +68,8 @@ int effective_cores()
     if (quota > 0 && period > 0) n = std::min<long>(n, std::max<long>(1, (quota + period - 1) / period));
     return n;
 }
+
+namespace {
 
 bool same_params(const mvhp_stream_params_t &a, const mvhp_stream_params_t &b)
 {
@@ -105,6 +109,7 @@ struct PicResult {
     const uint8_t *yuv = nullptr, *rgb = nullptr;
     bool ready = false;      // final: the sink may take it
     bool parsed_ok = false;
+    bool kept = false;       // the sink answered 2: its output chunk stays referenced until release_picture()
 };
 
 struct DevBuf {
@@ -201,6 +206,9 @@ private:
     void close_batch(Batch *b);
     void release_batch(Batch *b);
     void put_out(OutChunk *oc);
+public:
+    void release_picture(int seq);   // any thread
+private:
     bool grow(Pinned &p, size_t need);   // no lock needed
     int batch_capacity(const mvhp_stream_params_t &p, int remaining) const;
     int chunk_pictures(const mvhp_stream_params_t &p) const;
@@ -225,6 +233,9 @@ private:
     bool sink_waiting_ = false;
     int pos_ = 0;                 // next position of `order` the feeder has not issued yet
     int issued_ = 0, consumed_ = 0, ok_ = 0, failed_ = 0;
+    int kept_ = 0;                // pictures a sink kept (verdict 2) and has not released yet
+    int in_sink_ = -1;            // the picture whose sink callback is running
+    bool released_early_ = false; // ... and was given back by another thread meanwhile
     int next_batch_id_ = 0;
     std::vector<PicResult> results_;
     std::map<int, std::unique_ptr<Batch>> batches_;
@@ -791,6 +802,21 @@ void Engine::launcher(int k)
     }
 }
 
+void Engine::release_picture(int seq)
+{
+    {
+        std::lock_guard<std::mutex> l(mu_);
+        if (seq >= 0 && seq == in_sink_) { released_early_ = true; return; }   // its callback is still running: see the sink loop
+        if (seq < 0 || (size_t)seq >= results_.size() || !results_[(size_t)seq].kept) return;
+        PicResult &r = results_[(size_t)seq];
+        r.kept = false;
+        if (r.oc && --r.oc->refs == 0) put_out(r.oc);
+        r.oc = nullptr;
+        kept_--;
+    }
+    cv_.notify_all();
+}
+
 void Engine::put_out(OutChunk *oc)
 {
     free_out_.push_back(oc);
@@ -961,6 +987,8 @@ int Engine::decode(const mvhp_stream &s, const int *order, int n_order, int want
                 sink_waiting_ = false;
             }
             r = results_[(size_t)next];
+            in_sink_ = next;
+            released_early_ = false;
         }
         if (next == 0) first_picture_s_ = now_s() - t_start;
         int verdict = (r.rc == MVHP_SUCCESS) ? 1 : 0;
@@ -972,8 +1000,16 @@ int Engine::decode(const mvhp_stream &s, const int *order, int n_order, int want
         bool wake = false;
         {
             std::lock_guard<std::mutex> l(mu_);
-            if (r.oc && --r.oc->refs == 0) { put_out(r.oc); wake = true; }   // an output chunk for the downloader
-            results_[(size_t)next].oc = nullptr;
+            in_sink_ = -1;
+            if (verdict == 2 && r.rc == MVHP_SUCCESS && r.oc && !released_early_) {   // kept by the sink: the chunk stays out until
+                results_[(size_t)next].kept = true;                                    // release_picture(next)
+                kept_++;
+                verdict = 1;
+            } else {   // (released_early_: the other thread was done with it before the callback had returned)
+                if (verdict == 2) verdict = (r.rc == MVHP_SUCCESS) ? 1 : 0;
+                if (r.oc && --r.oc->refs == 0) { put_out(r.oc); wake = true; }   // an output chunk for the downloader
+                results_[(size_t)next].oc = nullptr;
+            }
             consumed_++;
             if (r.rc == MVHP_SUCCESS && verdict == 1) ok_++;
             else { failed_++; wake = true; }                                  // the allowance grew: the feeder may issue another picture
@@ -988,6 +1024,10 @@ int Engine::decode(const mvhp_stream &s, const int *order, int n_order, int want
     }
     cv_.notify_all();
     for (auto &t : th) t.join();
+    {   // pictures the sink kept (verdict 2) live in this engine's output chunks: the call ends when the last one is back
+        std::unique_lock<std::mutex> l(mu_);
+        cv_.wait(l, [&] { return kept_ == 0; });
+    }
     {
         std::lock_guard<std::mutex> l(mu_);
         batches_.clear();
@@ -1032,6 +1072,7 @@ Engine *engine_create(const DeviceApi &api, const mvhp_engine_opts_t *opts, std:
 }
 
 void engine_destroy(Engine *e) { delete e; }
+void engine_release_picture(Engine *e, int seq) { e->release_picture(seq); }
 
 int engine_decode(Engine *e, const mvhp_stream &s, const int *order, int n_order, int wanted, int out_mask,
                   mvhp_picture_sink_t sink, void *user, mvhp_decode_stats_t *stats, std::string &err)
@@ -1069,6 +1110,11 @@ MVHP_EXPORT void mvhp_engine_destroy(mvhp_engine_t *h)
     if (!h) return;
     mvengine::engine_destroy(h->e);
     delete h;
+}
+
+MVHP_EXPORT void mvhp_engine_release_picture(mvhp_engine_t *h, int seq)
+{
+    if (h) mvengine::engine_release_picture(h->e, seq);
 }
 
 MVHP_EXPORT int mvhp_engine_decode(mvhp_engine_t *h, const mvhp_stream_t *s, const int *order, int n_order, int wanted,

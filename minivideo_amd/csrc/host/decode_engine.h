@@ -49,6 +49,8 @@ class Engine;
 
 Engine *engine_create(const DeviceApi &api, const mvhp_engine_opts_t *opts, std::string &err);
 void    engine_destroy(Engine *e);
+void    engine_release_picture(Engine *e, int seq);
+int     effective_cores();   // hardware threads cut down to the container's CPU quota
 int     engine_decode(Engine *e, const mvhp_stream &s, const int *order, int n_order, int wanted, int out_mask,
                       mvhp_picture_sink_t sink, void *user, mvhp_decode_stats_t *stats, std::string &err);
 

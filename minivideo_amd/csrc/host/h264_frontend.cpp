@@ -14,43 +14,48 @@ namespace h264 {
 // ---------------------------------------------------------------------------
 int index_annexb(const uint8_t *data, size_t size, std::vector<EsSample> &out)
 {
+    // What the reference's byte-at-a-time scan accepts (esparser.c:40-143), found by hopping from one 0x01 byte to the next
+    // (memchr: a 1080p stream has one every ~256 bytes; the byte loop this replaces took 0.2 s on a 200-MB file, twice per
+    // mini_thumbnailer run):
+    //   * a sample starts behind 00 00 00 01 (at least three zero bytes, esparser.c:78) when the next byte is 0x65 / 0x67 /
+    //     0x68 (esparser.c:82) and the 0x01 lies more than 32 bytes before the end of the file (esparser.c:65);
+    //   * its NAL unit ends at the first 00 00 01 behind its header byte -- anywhere up to the end of the file -- with the
+    //     zero bytes in front of that trimmed; a sample runs to the next sample's first byte.
     out.clear();
     if (!data) return RC_FAILURE;
-    const int64_t limit = (int64_t)size - 32; // esparser.c:65: the scan stops 32 bytes before EOF
-    int64_t off = 0;
-    int zeros = 0;
-    while (off < limit) {
-        const uint8_t b = data[off++];
-        if (b == 0x00) {
-            zeros++;
-        } else {
-            if (b == 0x01 && zeros > 2) { // needs >= 3 zero bytes (esparser.c:78)
-                const uint8_t nb = data[off];
-                if (nb == 0x65 || nb == 0x67 || nb == 0x68) { // esparser.c:82
-                    EsSample s;
-                    s.offset = (size_t)off;
-                    s.nal_unit_type = nb & 31;
-                    s.nal_ref_idc = (nb >> 5) & 3;
-                    s.is_idr = (nb == 0x65);
-                    if (!out.empty()) out.back().sample_size = s.offset - out.back().offset;
-                    out.push_back(s);
-                }
+    const int64_t limit = (int64_t)size - 32;
+    bool open = false;   // the last sample of `out` has no end yet
+    auto close_at = [&](size_t end) {
+        const size_t beg = out.back().offset;
+        while (end > beg + 1 && data[end - 1] == 0) end--;
+        out.back().nal_size = end - beg;
+        open = false;
+    };
+    size_t from = 0;
+    while (from < size) {
+        const uint8_t *hit = static_cast<const uint8_t *>(memchr(data + from, 0x01, size - from));
+        if (!hit) break;
+        const size_t p = (size_t)(hit - data);
+        from = p + 1;
+        if (p < 2 || data[p - 1] != 0 || data[p - 2] != 0) continue;
+        if (open && p - 2 >= out.back().offset + 1) close_at(p - 2);
+        if (p >= 3 && data[p - 3] == 0 && (int64_t)p < limit) {
+            const uint8_t nb = data[p + 1];
+            if (nb == 0x65 || nb == 0x67 || nb == 0x68) {
+                EsSample s;
+                s.offset = p + 1;
+                s.nal_unit_type = nb & 31;
+                s.nal_ref_idc = (nb >> 5) & 3;
+                s.is_idr = (nb == 0x65);
+                if (!out.empty()) out.back().sample_size = s.offset - out.back().offset;
+                out.push_back(s);
+                open = true;
             }
-            zeros = 0;
         }
     }
     if (out.empty()) return RC_FAILURE;
     out.back().sample_size = size - out.back().offset;
-    // true NAL extent: up to the next start code prefix, trailing zero bytes trimmed
-    for (size_t i = 0; i < out.size(); i++) {
-        const size_t beg = out[i].offset, lim = beg + out[i].sample_size;
-        size_t end = lim;
-        for (size_t p = beg + 1; p + 2 < lim; p++) {
-            if (data[p] == 0 && data[p + 1] == 0 && data[p + 2] == 1) { end = p; break; }
-        }
-        while (end > beg + 1 && data[end - 1] == 0) end--;
-        out[i].nal_size = end - beg;
-    }
+    if (open) close_at(size);
     return RC_SUCCESS;
 }
 

@@ -3,6 +3,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -29,7 +30,9 @@ int mvhp_stream::build(std::string &err)
     for (size_t i = 0; i < samples.size(); i++) {
         const EsSample &s = samples[i];
         if (s.nal_size < 2) continue;
-        unescape_rbsp(data + s.offset + 1, s.nal_size - 1, rbsp);
+        // (of a slice only first_mb_in_slice, slice_type and pic_parameter_set_id are read here: three ue(v) of at most 65
+        // bits each -- the picture's 200 KB are unescaped by the thread that decodes it, not by this loop)
+        unescape_rbsp(data + s.offset + 1, s.nal_unit_type == 5 ? std::min<size_t>(s.nal_size - 1, 64) : s.nal_size - 1, rbsp);
         BitReader br(rbsp.data(), rbsp.size());
         std::string e;
         if (s.nal_unit_type == 7) {

@@ -19,10 +19,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CLI = os.path.join(ROOT, "minivideo_amd", "mini_thumbnailer")
 
 
-def _run(tmp_path, stream, name, *args):
+def _run(tmp_path, stream, name, *args, env=None):
     path = tmp_path / name
     stream.tofile(path)
-    r = subprocess.run([CLI, "-i", str(path), *args], cwd=tmp_path, capture_output=True, text=True, timeout=120)
+    r = subprocess.run([CLI, "-i", str(path), *args], cwd=tmp_path, capture_output=True, text=True, timeout=120,
+                       env=dict(os.environ, **env) if env else None)
     assert r.returncode == 0, r.stderr
     assert "decode did not succeed" not in r.stderr, r.stderr
     return r
@@ -110,6 +111,44 @@ def test_cli_yuv420_multi(tmp_path, profile):
     for k in range(F):
         got = np.fromfile(tmp_path / f"clip_{k}.yuv", np.uint8)
         assert np.array_equal(got, exp[k][0]), k
+
+
+@pytest.mark.parametrize("writers", ["0", "1", "6"])
+@pytest.mark.parametrize("fmt", ["yuv420", "bmp"])
+def test_cli_file_writers(tmp_path, writers, fmt):
+    """round 3: minivideo_decode's sink keeps the picture and a pool of threads writes the files (MINIVIDEO_WRITERS, 0 = on
+    the calling thread as before): same names, same bytes, every picture once, whatever the pool size"""
+    W, H, F = 22, 14, 60
+    stream, packed = gen.make_stream(W, H, F, seed=61, profile="high")
+    r = _run(tmp_path, stream, "w.264", "-f", fmt, "-n", str(F), env={"MINIVIDEO_WRITERS": writers, "MINIVIDEO_STATS": "1"})
+    assert f"{writers} file writers" in r.stderr and f"{F} written" in r.stderr, r.stderr
+    exp = _expected(W, H, packed, want_rgb=(fmt == "bmp"))
+    for k in range(F):
+        if fmt == "bmp":
+            assert (tmp_path / f"w_{k}.bmp").read_bytes() == _bmp(exp[k][1], W * 16, H * 16), k
+        else:
+            assert np.array_equal(np.fromfile(tmp_path / f"w_{k}.yuv", np.uint8), exp[k][0]), k
+    assert not (tmp_path / f"w_{F}.{fmt[:3]}").exists()
+
+
+def test_cli_unwritable_directory_fails(tmp_path):
+    """every write fails (read-only working directory): the pool reports each file and the call fails, as the synchronous path does"""
+    import stat
+    stream, _ = gen.make_stream(6, 4, 8, seed=62, profile="baseline")
+    (tmp_path / "in").mkdir()
+    src = tmp_path / "in" / "x.264"
+    stream.tofile(src)
+    ro = tmp_path / "ro"
+    ro.mkdir()
+    os.chmod(ro, stat.S_IRUSR | stat.S_IXUSR)
+    try:
+        if os.access(ro, os.W_OK):
+            pytest.skip("running as a user that ignores directory permissions")
+        r = subprocess.run([CLI, "-i", str(src), "-f", "yuv420", "-n", "8"], cwd=ro, capture_output=True, text=True, timeout=120)
+        assert r.stderr.count("Unable to write") == 8, r.stderr
+        assert "decode did not succeed" in r.stderr, (r.stdout, r.stderr)
+    finally:
+        os.chmod(ro, stat.S_IRWXU)
 
 
 def test_cli_mp4_equals_es(tmp_path):

@@ -11,6 +11,9 @@
 
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -244,6 +247,64 @@ int main(int argc, char **argv)
         g_slow_host_alloc_us = 0;
         EXPECT(c.bad == 0 && c.ok == (int)order.size() && c.failed == 0 && st.batches_requeued == 1);
         EXPECT((int)st.pictures_issued > (int)order.size());   // the failed batch's pictures were entropy-decoded twice
+    }
+    {   // the sink keeps pictures (verdict 2) and two other threads give them back later (minivideo_decode's file writers):
+        // the memory must still hold the same picture at release time -- an output chunk that went back to the pool early
+        // would have been overwritten by a later download -- and the call must not return before the last release
+        std::vector<int> order;
+        for (int k = 0; k < 400; k++) order.push_back((k * 7) % n_idr);
+        mvhp_engine_opts_t o = base; o.contexts = 2; o.chunk_pictures = 3; o.batch_pictures = 9;
+        mvhp_engine_t *e = nullptr;
+        EXPECT(mvhp_engine_create(&o, &e) == MVHP_SUCCESS);
+        struct Kept { int seq; const uint8_t *yuv; uint64_t h; };
+        struct Keeper {
+            mvhp_engine_t *e; const mvhp_stream *s;
+            std::mutex mu; std::condition_variable cv; std::deque<Kept> q; bool closing = false;
+            std::atomic<int> released{0}, bad{0}; int calls = 0;
+        } kp;
+        kp.e = e; kp.s = &s;
+        auto keeper = [&kp] {
+            for (;;) {
+                Kept k;
+                {
+                    std::unique_lock<std::mutex> l(kp.mu);
+                    kp.cv.wait(l, [&] { return kp.closing || !kp.q.empty(); });
+                    if (kp.q.empty()) return;
+                    k = kp.q.front(); kp.q.pop_front();
+                }
+                if (k.seq % 3) std::this_thread::sleep_for(std::chrono::microseconds(300));
+                uint64_t got = 0;
+                memcpy(&got, k.yuv, 8);
+                if (got != k.h || k.yuv[8] != 0x5a) kp.bad++;
+                kp.released++;
+                mvhp_engine_release_picture(kp.e, k.seq);
+            }
+        };
+        std::thread t1(keeper), t2(keeper);
+        auto sink = [](void *u, int seq, int idr, int rc, const char *, const mvhp_stream_params_t *p, const uint8_t *yuv, const uint8_t *) {
+            Keeper &x = *static_cast<Keeper *>(u);
+            x.calls++;
+            if (rc != MVHP_SUCCESS) { x.bad++; return 0; }
+            std::vector<uint8_t> packed(mvhp_packed_frame_bytes(p));
+            std::string er;
+            if (x.s->decode_packed(idr, packed.data(), packed.size(), er) != h264::RC_SUCCESS) { x.bad++; return 0; }
+            const uint64_t h = checksum(packed.data(), packed.size());
+            if (seq % 5 == 4) return 1;   // (some pictures are not kept: both kinds share chunks)
+            { std::lock_guard<std::mutex> l(x.mu); x.q.push_back(Kept{seq, yuv, h}); }
+            x.cv.notify_one();
+            if (seq % 6 == 0) std::this_thread::sleep_for(std::chrono::microseconds(500));   // released before this returns
+            return 2;
+        };
+        mvhp_decode_stats_t st;
+        EXPECT(mvhp_engine_decode(e, &s, order.data(), (int)order.size(), (int)order.size(), 0, sink, &kp, &st) == MVHP_SUCCESS);
+        const int released_at_return = kp.released.load();
+        { std::lock_guard<std::mutex> l(kp.mu); kp.closing = true; }
+        kp.cv.notify_all();
+        t1.join(); t2.join();
+        mvhp_engine_release_picture(e, 3);   // a stale release is ignored
+        mvhp_engine_destroy(e);
+        printf("%-28s calls=%d kept=%d bad=%d ok=%u\n", "kept pictures", kp.calls, released_at_return, kp.bad.load(), st.pictures_ok);
+        EXPECT(kp.bad == 0 && kp.calls == 400 && released_at_return == 320 && st.pictures_ok == 400);
     }
     {   // the sink stops the decode
         mvhp_engine_opts_t o = base; o.contexts = 2; o.chunk_pictures = 2; o.batch_pictures = 4;
