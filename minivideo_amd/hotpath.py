@@ -274,6 +274,8 @@ class Engine:
         L.mvhp_engine_decode.restype = C.c_int
         L.mvhp_engine_decode.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, SINK_T,
                                          C.c_void_p, C.POINTER(DecodeStats)]
+        L.mvhp_engine_release_picture.restype = None
+        L.mvhp_engine_release_picture.argtypes = [C.c_void_p, C.c_int]
         o = EngineOpts(contexts, host_threads, batch_pictures, chunk_pictures, fail_context, first_device)
         o.reserved[0] = 1 if placed else 0   # bit 0: batch buffers from mvhp_placed_alloc_sets (same as MINIVIDEO_PLACED=1)
         h = C.c_void_p()
@@ -292,9 +294,14 @@ class Engine:
         except Exception:
             pass
 
+    def release_picture(self, seq):
+        """gives back a picture whose sink call answered 2 (any thread; the decode call returns when the last one is back)"""
+        self._L.mvhp_engine_release_picture(self._h, int(seq))
+
     def decode(self, stream_handle, order, wanted=None, want_rgb=False, sink=None):
-        """sink(seq, idr, rc, err, params, yuv ndarray | None, rgb ndarray | None) -> 1 accept / 0 reject / -1 stop;
-        the arrays are views of page-locked memory valid only during the call.  Returns (rc, stats dict)."""
+        """sink(seq, idr, rc, err, params, yuv ndarray | None, rgb ndarray | None) -> 1 accept / 0 reject / -1 stop /
+        2 accept and keep until release_picture(seq); the arrays are views of page-locked memory valid only during the call
+        (or until the release).  Returns (rc, stats dict)."""
         order = (C.c_int * len(order))(*order)
         st = DecodeStats()
 

@@ -220,3 +220,50 @@ def test_engine_rgb_only_skips_the_plane_download():
     for k in range(F):
         assert got[k][0] == 1 and got[k][1]
         assert np.array_equal(got[k][2], loader.recon(p, packed[k], 1, want_rgb=True)[1]), k
+
+
+def test_engine_kept_pictures_are_valid_until_released():
+    """round 3: a sink that answers 2 keeps the picture; a second thread compares it with the oracle LATER and gives it back
+    (mvhp_engine_release_picture).  Small chunks and batches so that kept pictures pin output chunks the downloader wants."""
+    import queue
+    import threading
+    W, H, F = 20, 12, 90
+    stream, packed = gen.make_stream(W, H, F, seed=97, profile="high")
+    p = StreamParams(W, H, 0, 0, 0)
+    eng = Engine(contexts=2, chunk_pictures=4, batch_pictures=12)
+    q = queue.Queue()
+    bad, released = [], []
+
+    def checker():
+        while True:
+            item = q.get()
+            if item is None:
+                return
+            seq, yuv, rgb = item
+            ref_yuv, ref_rgb = loader.recon(p, packed[seq], 1, want_rgb=True)     # (takes longer than the pipeline needs per picture)
+            if not (np.array_equal(yuv, ref_yuv) and np.array_equal(rgb, ref_rgb)):
+                bad.append(seq)
+            released.append(seq)
+            eng.release_picture(seq)
+
+    th = threading.Thread(target=checker)
+    th.start()
+
+    def sink(seq, idr, rc, err, prm, yuv, rgb):
+        if rc != 1:
+            bad.append(seq)
+            return 0
+        if seq % 4 == 3:
+            return 1
+        q.put((seq, yuv, rgb))     # views, not copies
+        return 2
+
+    with Stream(stream) as s:
+        rc, st = eng.decode(s.h, list(range(F)), want_rgb=True, sink=sink)
+        n_released_at_return = len(released)
+    q.put(None)
+    th.join()
+    eng.close()
+    kept = F - F // 4
+    assert rc == 1 and st["pictures_ok"] == F and not bad
+    assert n_released_at_return == kept     # the call waited for the last kept picture
