@@ -870,9 +870,21 @@ struct CavlcTables {
     uint16_t coeff_token_cdc[256];   // chroma DC (nC = -1): next 8 bits -> len | total << 4 | trailing_ones << 8
     uint8_t  total_zeros_cdc[3][8];  // next 3 bits -> len | value << 4
     uint8_t  run_before[6][8];       // zerosLeft 1..6: next 3 bits -> len | value << 4
+    // a level whose prefix and suffix fit the next 8 bits (9.2.2.1 with level_prefix < 14: levelCode = (prefix << suffixLength)
+    // + suffix), per suffixLength 0..6: len | levelCode << 8; 0 = longer than 8 bits or an escape, decoded the long way
+    uint16_t level8[7][256];
     CavlcTables()
     {
         memset(this, 0, sizeof(*this));
+        for (int sl = 0; sl < 7; sl++)
+            for (int v = 0; v < 256; v++) {
+                int prefix = 0;
+                while (prefix < 8 && !(v & (0x80 >> prefix))) prefix++;
+                const int len = prefix + 1 + sl;
+                if (prefix >= 8 || len > 8) continue;
+                const int suffix = (v >> (8 - len)) & ((1 << sl) - 1);
+                level8[sl][v] = (uint16_t)(len | (((prefix << sl) + suffix) << 8));
+            }
         for (int tab = 0; tab < 3; tab++)
             for (int t = 0; t < 4; t++)
                 for (int n = 0; n < 17; n++) {
@@ -948,16 +960,27 @@ int PictureDecoder::residual_block_cavlc(int addr, int startIdx, int endIdx, int
     if (total == 0) return RC_SUCCESS;
     if (total > maxNumCoeff) return RC_SUCCESS; // silently skipped (:218)
 
-    int level[16], run[16];
+    int level[16 + 3];
     int suffixLength = (total > 10 && t1s < 3) ? 1 : 0;
-    for (int i = 0; i < total; i++) {
-        if (i < t1s) {
-            level[i] = 1 - 2 * (int)bw.bit();
+    {   // trailing ones: up to three sign bits, read at once
+        const uint32_t sgn = bw.peek(3);
+        level[0] = 1 - 2 * (int)((sgn >> 2) & 1u);
+        level[1] = 1 - 2 * (int)((sgn >> 1) & 1u);
+        level[2] = 1 - 2 * (int)(sgn & 1u);
+        bw.skip(t1s);
+    }
+    int first_adjust = (t1s < 3) ? 2 : 0;   // the first level behind fewer than three trailing ones: levelCode += 2
+    for (int i = t1s; i < total; i++) {
+        int levelCode;
+        const uint16_t e = g_cavlc.level8[suffixLength][bw.peek(8)];
+        if (e) {
+            bw.skip((int)(e & 255u));
+            levelCode = (int)(e >> 8);
         } else {
             const int level_prefix = bw.leading_zeros32();
             if (level_prefix > 28 || bw.overrun()) return RC_FAILURE;
             bw.skip(level_prefix + 1);
-            int levelCode = (level_prefix < 15 ? level_prefix : 15) << suffixLength;
+            levelCode = (level_prefix < 15 ? level_prefix : 15) << suffixLength;
             if (suffixLength > 0 || level_prefix >= 14) {
                 int size = suffixLength;
                 if (level_prefix == 14 && suffixLength == 0) size = 4;
@@ -966,16 +989,18 @@ int PictureDecoder::residual_block_cavlc(int addr, int startIdx, int endIdx, int
             }
             if (level_prefix >= 15 && suffixLength == 0) levelCode += 15;
             if (level_prefix >= 16) levelCode += (1 << (level_prefix - 3)) - 4096;
-            if (i == t1s && t1s < 3) levelCode += 2;
-            level[i] = (levelCode % 2 == 0) ? ((levelCode + 2) >> 1) : ((-levelCode - 1) >> 1);
-            if (suffixLength == 0) suffixLength = 1;
-            if (abs(level[i]) > (3 << (suffixLength - 1)) && suffixLength < 6) suffixLength++;
         }
+        levelCode += first_adjust;
+        first_adjust = 0;
+        const int sign = -(levelCode & 1), mag = (levelCode + 2) >> 1;   // even: (levelCode + 2) >> 1, odd: (-levelCode - 1) >> 1
+        level[i] = (mag ^ sign) - sign;
+        suffixLength += (suffixLength == 0);
+        suffixLength += (mag > (3 << (suffixLength - 1))) & (suffixLength < 6);
     }
     int zerosLeft = 0;
     if (total < endIdx - startIdx + 1) {
         int tz;
-        if (cat == CAT_CHROMA_DC_CB || cat == CAT_CHROMA_DC_CR) {
+        if (nC == -1) {
             const uint8_t e = g_cavlc.total_zeros_cdc[total - 1][bw.peek(3)];
             if (!e) return RC_FAILURE;
             bw.skip((int)(e & 15u));
@@ -988,38 +1013,36 @@ int PictureDecoder::residual_block_cavlc(int addr, int startIdx, int endIdx, int
         }
         zerosLeft = tz;
     }
-    for (int i = 0; i < total - 1; i++) {
-        if (zerosLeft > 0) {
-            int rb;
-            if (zerosLeft <= 6) {
-                const uint8_t e = g_cavlc.run_before[zerosLeft - 1][bw.peek(3)];
-                if (!e) return RC_FAILURE;
-                bw.skip((int)(e & 15u));
-                rb = e >> 4;
-            } else { // Table 9-10, zerosLeft > 6: 3-bit codes 111..001 = 0..6, then 0001 = 7, 00001 = 8, ...
-                const uint32_t v3 = bw.peek(3);
-                if (v3) { bw.skip(3); rb = 7 - (int)v3; }
-                else {
-                    const int lz = bw.leading_zeros32();
-                    if (lz > 10) return RC_FAILURE;
-                    bw.skip(lz + 1);
-                    rb = lz + 4;
-                }
+    // run_before (9.2.3): level[0] is the highest-frequency coefficient, at index total - 1 + total_zeros; every run_before
+    // moves the next one down.  Positions first, then the levels are handed over in ascending order as before.
+    int pos[16];
+    int idx = total - 1 + zerosLeft;
+    if (startIdx + idx > endIdx || startIdx + idx >= 64) return RC_FAILURE;
+    int i = 0;
+    for (; i < total - 1 && zerosLeft > 0; i++) {
+        int rb;
+        if (zerosLeft <= 6) {
+            const uint8_t e = g_cavlc.run_before[zerosLeft - 1][bw.peek(3)];
+            if (!e) return RC_FAILURE;
+            bw.skip((int)(e & 15u));
+            rb = e >> 4;
+        } else { // Table 9-10, zerosLeft > 6: 3-bit codes 111..001 = 0..6, then 0001 = 7, 00001 = 8, ...
+            const uint32_t v3 = bw.peek(3);
+            if (v3) { bw.skip(3); rb = 7 - (int)v3; }
+            else {
+                const int lz = bw.leading_zeros32();
+                if (lz > 10) return RC_FAILURE;
+                bw.skip(lz + 1);
+                rb = lz + 4;
             }
-            run[i] = rb;
-        } else {
-            run[i] = 0;
         }
-        zerosLeft -= run[i];
+        zerosLeft -= rb;
         if (zerosLeft < 0) return RC_FAILURE;
+        pos[i] = idx;
+        idx -= rb + 1;
     }
-    run[total - 1] = zerosLeft;
-    int coeffNum = -1;
-    for (int i = total - 1; i >= 0; i--) {
-        coeffNum += run[i] + 1;
-        if (startIdx + coeffNum > endIdx || startIdx + coeffNum >= 64) return RC_FAILURE;
-        put(startIdx + coeffNum, level[i]);
-    }
+    for (; i < total; i++) pos[i] = idx--;   // no zeros left: the rest are adjacent (the last one sits on what is left)
+    for (i = total - 1; i >= 0; i--) put(startIdx + pos[i], level[i]);
     return RC_SUCCESS;
 }
 

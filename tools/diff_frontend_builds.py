@@ -1,0 +1,67 @@
+"""Developer aid (CPU): two builds of libminivideo.so against each other -- return codes, packed records and compact bytes of
+every picture of generated and bit-flipped streams (all profiles, reference and MVHP_STREAM_SPEC mode).  Used when the entropy
+decoders are rewritten for speed: the previous build is the witness.
+usage: diff_frontend_builds.py [seed] [cases]   (old library: /tmp/libmv_old.so = a copy of the build before the change)"""
+import ctypes as C, sys, numpy as np
+sys.path.insert(0, "/root/repo")
+from minivideo_amd import gen
+from minivideo_amd.hotpath import StreamParams
+
+def load(path):
+    L = C.CDLL(path)
+    L.mvhp_stream_open_ex.argtypes = [C.c_void_p, C.c_size_t, C.c_uint32, C.POINTER(C.c_void_p)]
+    L.mvhp_stream_close.argtypes = [C.c_void_p]
+    L.mvhp_stream_idr_count.argtypes = [C.c_void_p]
+    L.mvhp_stream_params.argtypes = [C.c_void_p, C.c_int, C.POINTER(StreamParams)]
+    L.mvhp_stream_decode_packed.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
+    L.mvhp_stream_decode_compact.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    return L
+
+def run(L, data, spec):
+    h = C.c_void_p()
+    out = []
+    if L.mvhp_stream_open_ex(data.ctypes.data, data.size, 1 if spec else 0, C.byref(h)) != 1:
+        return ["open failed"]
+    n = L.mvhp_stream_idr_count(h)
+    for k in range(n):
+        p = StreamParams()
+        if L.mvhp_stream_params(h, k, C.byref(p)) != 1:
+            out.append(("noparams",)); continue
+        nb = p.width_mbs * p.height_mbs
+        packed = np.zeros(nb * 800, np.uint8)
+        rc = L.mvhp_stream_decode_packed(h, k, packed.ctypes.data, packed.size)
+        comp = np.zeros(nb * 872 + 4096, np.uint8)
+        used = C.c_size_t(0)
+        rc2 = L.mvhp_stream_decode_compact(h, k, comp.ctypes.data, comp.size, C.byref(used))
+        out.append((rc, packed.tobytes() if rc == 1 else b"", rc2, comp[:used.value].tobytes() if rc2 == 1 else b""))
+    L.mvhp_stream_close(h)
+    return out
+
+old, new = load("/tmp/libmv_old.so"), load("/root/repo/minivideo_amd/libminivideo.so")
+rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
+cases = int(sys.argv[2]) if len(sys.argv) > 2 else 300
+n_pic = n_ok = 0
+for c in range(cases):
+    prof = ["baseline", "high_cavlc", "main_cavlc", "baseline"][c % 4] if c % 7 else "high"
+    W, H, F = int(rng.integers(1, 12)), int(rng.integers(1, 9)), int(rng.integers(1, 4))
+    spec = (c % 5 == 0)
+    try:
+        if spec:
+            stream, _, _ = gen.make_stream_ex(W, H, F, seed=int(rng.integers(1 << 30)), profile=prof if prof != "main_cavlc" else "baseline", slices=int(rng.integers(1, 4)), pcm_permille=int(rng.integers(0, 100)), scaling=int(rng.integers(0, 4)) if prof.startswith("high") else 0)
+        else:
+            stream, _ = gen.make_stream(W, H, F, seed=int(rng.integers(1 << 30)), profile=prof if prof != "main_cavlc" else "baseline", dense=bool(c % 3))
+    except Exception as e:
+        print("gen", e); continue
+    for m in range(6):
+        data = stream.copy()
+        if m:
+            for _ in range(int(rng.integers(1, 5))):
+                pos = int(rng.integers(0, data.size))
+                data[pos] ^= np.uint8(1 << int(rng.integers(0, 8)))
+        a, b = run(old, data, spec), run(new, data, spec)
+        if a != b:
+            print("MISMATCH case", c, "mutation", m, prof, W, H, F, spec)
+            np.save("/tmp/mismatch.npy", data)
+            sys.exit(1)
+        n_pic += len(a); n_ok += sum(1 for x in a if isinstance(x, tuple) and x[0] == 1)
+print("identical:", cases, "cases x 6 variants,", n_pic, "pictures,", n_ok, "decoded ok")
