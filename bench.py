@@ -65,6 +65,7 @@ def parse_args():
     ap.add_argument("--cpu-seconds", type=float, default=5.0, help="budget of each of the four CPU baseline legs")
     ap.add_argument("--e2e-pictures", type=int, default=-1,
                     help="pictures of the end-to-end leg, in total over the ranks (-1: 2048 per rank, or P with --strong; 0: skip)")
+    ap.add_argument("--e2e-repeats", type=int, default=3, help="timed calls of the end-to-end leg (the median is reported)")
     ap.add_argument("--e2e-batch", type=int, default=0, help="pictures per launch in the end-to-end leg (0: engine default)")
     ap.add_argument("--placement-trials", type=int, default=3,
                     help="N = 1 only: re-time the launch on this many sets of ordinarily allocated buffers (reported, not part of value)")
@@ -260,15 +261,25 @@ def end_to_end(args, params, stream, n_distinct, rec, want_rgb, total, rank, wor
     rc0, st0 = eng.decode(h, order, want_rgb=want_rgb)
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    rc, st = eng.decode(h, order, want_rgb=want_rgb, sink=sink)
-    torch.cuda.synchronize(dev)
-    wall = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([wall], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        wall = float(t.item())
+    # three timed calls, each bracketed like the kernel leg (barrier, synchronize, MAX over the ranks); the line reports the
+    # MEDIAN -- one 0.5-s call varies by several per cent from call to call on this pool -- and lists all three
+    calls, rc = [], 1
+    for rep in range(max(1, args.e2e_repeats)):
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        rc_i, st_i = eng.decode(h, order, want_rgb=want_rgb, sink=sink)
+        torch.cuda.synchronize(dev)
+        w_i = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([w_i], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            w_i = float(t.item())
+        calls.append((w_i, st_i))
+        rc = rc if rc_i == 1 and st_i["pictures_ok"] == len(order) else 0
+    wall, st = sorted(calls, key=lambda c: c[0])[len(calls) // 2]   # (the stage figures below are the median call's)
+    walls = [c[0] for c in calls]
     # the same job with RGB as the only output (what minivideo_decode asks for when it writes bmp / png / tga): a third of the
     # bytes cross the link on the way back
     torch.cuda.synchronize(dev)
@@ -278,7 +289,7 @@ def end_to_end(args, params, stream, n_distinct, rec, want_rgb, total, rank, wor
     wall_r = time.perf_counter() - t1
     eng.close()
     L.mvhp_stream_close(h)
-    ok = rc == 1 and st["pictures_ok"] == len(order) and rc_r == 1
+    ok = rc == 1 and rc_r == 1
     from oracle import loader   # every rank checks its own pictures (each rank decodes a stream of its own seed)
     for seq, (idr, yuv, rgb) in kept.items():
         ref, ref_rgb = loader.recon(params, rec[idr % n_distinct], 1, want_rgb=want_rgb)
@@ -303,7 +314,7 @@ def end_to_end(args, params, stream, n_distinct, rec, want_rgb, total, rank, wor
                 "(mvhp_engine_decode: entropy threads || H2D || kernels || D2H)",
         "pictures": total,
         "n_gpus": world,
-        "wall_s": wall,
+        "wall_s": wall, "wall_s_each": walls, "timed_calls": "median of %d calls on one engine, after its cold call" % len(walls),
         "outputs": "planes + RGB" if want_rgb else "planes",
         "rgb_only_rank0": None if st_r is None else {
             "value": mine * params.mbs / wall_r, "unit": "macroblocks/s", "wall_s": wall_r, "pictures": mine,

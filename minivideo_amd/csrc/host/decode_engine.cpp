@@ -165,12 +165,16 @@ struct RetryGroup {
     size_t pos = 0;
 };
 
+constexpr int kMaxDevBufs = 8;
+
 struct Ctx {
     DevCtx *dev = nullptr;
     int device = 0;
-    DevBuf bufs[3];   // three batches per context: one filling / uploading, one in the kernel, one downloading -- with two, the batch
-                      // after next could not be claimed until a download finished and the entropy threads ran out of chunk slots
-                      // (170 pictures took 90 ms instead of 44 to fill in the taper of a 2048-picture job)
+    DevBuf bufs[kMaxDevBufs];   // n_bufs of them in use.  Three batches per context is the minimum: one filling / uploading, one in
+                      // the kernel, one downloading -- with two, the batch after next could not be claimed until a download finished
+                      // and the entropy threads ran out of chunk slots (170 pictures took 90 ms instead of 44 to fill in the taper of
+                      // a 2048-picture job).  More (MINIVIDEO_DEVBUFS = 4...8) were measured in round 3: no gain (tools/e2e_devbufs_sweep.sh)
+    int n_bufs = 3;
     int open_batch = -1;
     std::deque<int> to_launch, to_download;
     bool fail_next = false;
@@ -211,6 +215,7 @@ public:
 private:
     bool grow(Pinned &p, size_t need);   // no lock needed
     int batch_capacity(const mvhp_stream_params_t &p, int remaining) const;
+    int planned_batch(int cap, int remaining, int batch_id) const;
     int chunk_pictures(const mvhp_stream_params_t &p) const;
     bool ensure_devbuf(Ctx &c, DevBuf &b, const Batch &bt, std::string &err);   // no lock needed
 
@@ -253,6 +258,7 @@ private:
     uint64_t alloc_host_bytes_ = 0, alloc_dev_bytes_ = 0;
     bool placed_ = false;    // MINIVIDEO_PLACED=1 / opts.reserved[0] & 1
     int job_cap_ = 1;        // the largest batch the running call can form (per context)
+    mvhp_stream_params_t job_params_{};   // ... of pictures of this size (the first picture's)
 };
 
 Engine::~Engine()
@@ -302,13 +308,14 @@ bool Engine::init(const mvhp_engine_opts_t *opts, std::string &err)
         ctx_[k].dev = api_.ctx_create(ctx_[k].device, err);
         if (!ctx_[k].dev) return false;
     }
-    // device memory one batch may take: half of what is free now, split over the three batch buffers (filling / in the kernel / downloading) of every context
+    // device memory one batch may take: half of what is free now, split over the batch buffers (filling / in the kernel / downloading / waiting for the download) of every context
     // that shares the device
     for (int k = 0; k < n_ctx; k++) {
         int sharers = 0;
         for (int j = 0; j < n_ctx; j++) sharers += ctx_[j].device == ctx_[k].device;
         const size_t free_b = api_.dev_free_bytes(ctx_[k].dev);
-        ctx_[k].mem_budget = free_b / 2 / 3 / (size_t)std::max(1, sharers);   // half of what is free, three batches
+        ctx_[k].n_bufs = std::max(3, std::min(kMaxDevBufs, env_int("MINIVIDEO_DEVBUFS", 3)));
+        ctx_[k].mem_budget = free_b / 2 / (size_t)ctx_[k].n_bufs / (size_t)std::max(1, sharers);   // half of what is free, over the batch buffers
     }
     return true;
 }
@@ -359,9 +366,17 @@ int Engine::batch_capacity(const mvhp_stream_params_t &p, int remaining) const
     cap = std::min(cap, mem_cap);
     for (const Ctx &c : ctx_)
         if (c.arena && c.arena_pictures > 0 && same_params(c.arena_params, p)) cap = std::min(cap, c.arena_pictures);
+    return planned_batch(cap, remaining, next_batch_id_);
+}
+
+// batches ramp up (the first pictures should not wait for a full-size batch to fill), run at the cap, and taper off (the
+// last batch's upload, kernel and download are the tail nobody overlaps with)
+int Engine::planned_batch(int cap, int remaining, int batch_id) const
+{
+    const int n_ctx = (int)ctx_.size();
     const int share = (remaining + n_ctx - 1) / n_ctx;
     if (opts_.batch_pictures > 0) return std::max(1, std::min(cap, share));   // an explicit batch size is taken as given
-    const int round = next_batch_id_ / n_ctx;                                   // batches each context has been given so far
+    const int round = batch_id / n_ctx;                                         // batches each context has been given so far
     const int ramp = round < 6 ? std::min(64 << round, cap) : cap;
     const int taper = std::max(64, (int)((remaining * 0.35 + n_ctx - 1) / n_ctx));
     return std::max(1, std::min(std::min(cap, ramp), std::min(share, taper)));
@@ -429,7 +444,10 @@ bool Engine::ensure_devbuf(Ctx &c, DevBuf &b, const Batch &bt, std::string &err)
         }
         return *ptr != nullptr;
     };
-    const size_t n = (size_t)bt.capacity;
+    // sized for the largest batch this call can form on a context, not for the batch at hand: the ramp and the taper hand a
+    // buffer batches of changing sizes, and every growth is a hipFree + hipMalloc in the middle of the pipeline (hipFree
+    // waits for the device) -- the second and third call of an engine still paid for that (0.55 s, then 0.51 s, same job)
+    const size_t n = (size_t)std::max(bt.capacity, (bt.params.width_mbs == job_params_.width_mbs && bt.params.height_mbs == job_params_.height_mbs) ? job_cap_ : 0);
     if (!need(&b.compact, &b.compact_cap, n * compact_slot_bytes(bt.params)) ||
         !need(&b.packed, &b.packed_cap, n * mvhp_packed_frame_bytes(&bt.params)) ||
         !need((void **)&b.yuv, &b.yuv_cap, n * mvhp_yuv_frame_bytes(&bt.params)) ||
@@ -658,8 +676,8 @@ bool Engine::pick_chunk(int k, InChunk **c, Batch **b)
         return true;
     }
     DevBuf *fb = nullptr;
-    for (DevBuf &d : cx.bufs)
-        if (!d.busy) { fb = &d; break; }
+    for (int i = 0; i < cx.n_bufs; i++)
+        if (!cx.bufs[i].busy) { fb = &cx.bufs[i]; break; }
     if (!fb) return false;
     for (auto &kv : batches_) {   // lowest id first: batches are claimed in the order they were opened
         Batch *nb = kv.second.get();
@@ -952,13 +970,21 @@ int Engine::decode(const mvhp_stream &s, const int *order, int n_order, int want
         for (int i = 0; i < n_order; i++)
             if (mvhp_stream_params(&s, order[i], &p0) == MVHP_SUCCESS) { C = chunk_pictures(p0); break; }
         in_limit_ = (size_t)std::max(3, (host_threads_ + C - 1) / C + 1 + n_ctx);
+        if (const int e = env_int("MINIVIDEO_IN_CHUNKS", 0)) in_limit_ = (size_t)std::max(2, std::min(64, e));   // developer aid
         {   // the largest batch this call can form on a context: what a placed arena is sized for
             int cap = opts_.batch_pictures > 0 ? opts_.batch_pictures : ((n_order_ >= 4096 * n_ctx) ? 2048 : 1024);
             const size_t per_pic = compact_slot_bytes(p0) + mvhp_packed_frame_bytes(&p0) + mvhp_yuv_frame_bytes(&p0) + mvhp_rgb_frame_bytes(&p0);
             size_t budget = ctx_[0].mem_budget;
             for (const Ctx &c : ctx_) budget = std::min(budget, c.mem_budget);
             cap = std::min<int>(cap, (int)std::min<size_t>(1 << 20, std::max<size_t>(1, budget / std::max<size_t>(1, per_pic))));
-            job_cap_ = std::max(1, std::min(cap, (wanted_ + n_ctx - 1) / n_ctx));
+            cap = std::max(1, std::min(cap, (wanted_ + n_ctx - 1) / n_ctx));
+            job_cap_ = 1;   // the largest batch the ramp / cap / taper will actually form when nothing fails
+            for (int rem = wanted_, id = 0; rem > 0; id++) {
+                const int b = planned_batch(cap, rem, id);
+                job_cap_ = std::max(job_cap_, b);
+                rem -= b;
+            }
+            job_params_ = p0;
         }
         out_limit_ = (size_t)(2 * n_ctx + 2);
     }
