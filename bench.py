@@ -395,10 +395,20 @@ def cli_cold(args, params, stream, n_distinct, rec):
     try:
         path = os.path.join(d, "clip.264")
         repeat_stream(stream, n_distinct, n).tofile(path)
-        t0 = time.perf_counter()
-        r = subprocess.run([exe, "-i", path, "-f", "yuv420", "-n", str(n)], cwd=d, capture_output=True, text=True, timeout=600,
-                           env=dict(os.environ, MINIVIDEO_STATS="1"))
-        wall = time.perf_counter() - t0
+        # three fresh processes (the files of one run are removed before the next); the MEDIAN run is reported: how long the HIP
+        # runtime takes to come up in a new process varies between 0.05 and 0.25 s on this pool
+        runs = []
+        for rep in range(3):
+            for f in os.listdir(d):
+                if f.endswith(".yuv"):
+                    os.unlink(os.path.join(d, f))
+            t0 = time.perf_counter()
+            r_i = subprocess.run([exe, "-i", path, "-f", "yuv420", "-n", str(n)], cwd=d, capture_output=True, text=True, timeout=600,
+                                 env=dict(os.environ, MINIVIDEO_STATS="1"))
+            runs.append((time.perf_counter() - t0, r_i))
+            if r_i.returncode != 0:
+                break
+        wall, r = sorted(runs, key=lambda x: x[0])[len(runs) // 2] if all(x[1].returncode == 0 for x in runs) else runs[-1]
         files = [f for f in os.listdir(d) if f.endswith(".yuv")]
         ok = r.returncode == 0 and len(files) == n
         for k in (0, n // 2, n - 1):
@@ -411,7 +421,7 @@ def cli_cold(args, params, stream, n_distinct, rec):
         call = [l for l in r.stderr.splitlines() if l.startswith("[minivideo] decode call:") or l.startswith("[minivideo] parse call:")]
         return {"what": "mini_thumbnailer -f yuv420 -n %d, a fresh process: stream file on tmpfs -> .yuv files on tmpfs" % n,
                 "value": n * params.mbs / wall, "unit": "macroblocks/s", "pictures": n, "wall_s": wall,
-                "files_equal_oracle": ok, "library_stats": stats[-1] if stats else None,
+                "wall_s_each": [x[0] for x in runs], "files_equal_oracle": ok, "library_stats": stats[-1] if stats else None,
                 "library_calls": call or None}
     finally:
         shutil.rmtree(d, ignore_errors=True)
