@@ -49,7 +49,7 @@ for c in range(cases):
         if spec:
             stream, _, _ = gen.make_stream_ex(W, H, F, seed=int(rng.integers(1 << 30)), profile=prof if prof != "main_cavlc" else "baseline", slices=int(rng.integers(1, 4)), pcm_permille=int(rng.integers(0, 100)), scaling=int(rng.integers(0, 4)) if prof.startswith("high") else 0)
         else:
-            stream, _ = gen.make_stream(W, H, F, seed=int(rng.integers(1 << 30)), profile=prof if prof != "main_cavlc" else "baseline", dense=bool(c % 3))
+            stream, _ = gen.make_stream(W, H, F, seed=int(rng.integers(1 << 30)), profile=prof if prof != "main_cavlc" else "baseline", dense=bool(c % 3), max_level=int(rng.choice([32, 300, 2000, 30000])), qp_range=(int(rng.integers(0, 30)), int(rng.integers(30, 52))))
     except Exception as e:
         print("gen", e); continue
     for m in range(6):

@@ -47,6 +47,25 @@ while time.time() - t0 < budget:
             print("FRONT END != GENERATOR", W, H, n, sprof, flush=True)
             sys.exit(1)
         n_spec = globals().get("n_spec", 0) + 1
+    elif rng.random() < 0.2:   # reference-mode streams through the host front end (CAVLC and CABAC), then the compact path too
+        from minivideo_amd import gen
+        from tests.compact import decode_compact, expand_compact
+        from tests.util import Stream
+        sprof = ["baseline", "main", "high", "high_cavlc"][int(rng.integers(0, 4))]
+        W, H, n = min(W, 30), min(H, 20), min(n, 4)
+        stream, packed = gen.make_stream(W, H, n, seed=int(rng.integers(0, 1 << 30)), profile=sprof, dense=(dens == "dense"), qp_range=(lo, hi), max_level=int(rng.choice([32, 300, 2000])))
+        with Stream(stream) as st:
+            params = st.params(0)
+            rec = np.stack([st.packed(k)[1] for k in range(n)])
+            for k in range(n):
+                rc2, used, buf = decode_compact(st, k)
+                if rc2 != 1 or not np.array_equal(expand_compact(buf[:used], W * H).reshape(-1), rec[k].reshape(-1)):
+                    print("COMPACT != PACKED", W, H, n, sprof, k, flush=True)
+                    sys.exit(1)
+        if not np.array_equal(rec.reshape(packed.shape), packed):
+            print("FRONT END != GENERATOR", W, H, n, sprof, flush=True)
+            sys.exit(1)
+        n_ref = globals().get("n_ref", 0) + 1
     else:
         params, rec = synth_packed(W, H, n, seed=int(rng.integers(0, 1 << 30)), **kw)
     h.set_layout(layout); h.set_waves_per_picture(waves)
@@ -59,4 +78,4 @@ while time.time() - t0 < budget:
     if time.time() - t_print > 30:   # progress line (a silent GPU job is taken to be hung)
         t_print = time.time()
         print("... %d cases, %d macroblocks, %.0f s" % (n_cases, n_mb, time.time() - t0), flush=True)
-print("soak ok: %d cases (%d of them spec-mode streams), %d macroblocks, %.0f s" % (n_cases, globals().get("n_spec", 0), n_mb, time.time() - t0))
+print("soak ok: %d cases (%d of them spec-mode streams, %d reference-mode streams through the front end), %d macroblocks, %.0f s" % (n_cases, globals().get("n_spec", 0), globals().get("n_ref", 0), n_mb, time.time() - t0))
