@@ -49,7 +49,7 @@ while time.time() - t0 < budget:
         n_spec = globals().get("n_spec", 0) + 1
     elif rng.random() < 0.2:   # reference-mode streams through the host front end (CAVLC and CABAC), then the compact path too
         from minivideo_amd import gen
-        from tests.compact import decode_compact, expand_compact
+        from tests.compact import decode_compact, expand as expand_compact
         from tests.util import Stream
         sprof = ["baseline", "main", "high", "high_cavlc"][int(rng.integers(0, 4))]
         W, H, n = min(W, 30), min(H, 20), min(n, 4)
@@ -59,7 +59,7 @@ while time.time() - t0 < budget:
             rec = np.stack([st.packed(k)[1] for k in range(n)])
             for k in range(n):
                 rc2, used, buf = decode_compact(st, k)
-                if rc2 != 1 or not np.array_equal(expand_compact(buf[:used], W * H).reshape(-1), rec[k].reshape(-1)):
+                if rc2 != 1 or not np.array_equal(expand_compact(buf, W * H).reshape(-1), rec[k].reshape(-1)):
                     print("COMPACT != PACKED", W, H, n, sprof, k, flush=True)
                     sys.exit(1)
         if not np.array_equal(rec.reshape(packed.shape), packed):
