@@ -348,7 +348,8 @@ int Engine::chunk_pictures(const mvhp_stream_params_t &p) const
 // next: what matters is that downloads start early and that the job's last download is short.  So batches RAMP UP from 64
 // pictures, doubling, to the cap (the download of batch k hides behind the entropy work of batch k+1 as long as batches
 // do not shrink faster than the link is quicker than the entropy stage), and TAPER at the end (each takes at most 35 %
-// of what is left per context, down to 64): 64 128 256 512 381 248 161 105 68 64 61 for 2048 pictures on one context;
+// of what is left per context, down to one picture per entropy thread): 16 32 64 128 256 512 364 236 154 100 65 42 27 18 16 16 2
+// for 2048 pictures on one context and 16 threads (round 2 started and ended on 64);
 // long jobs run most of their pictures in 1024-picture launches.  Modelled wall for 2048 x 1080p: 0.56 s against 0.63 s
 // with 1024 512 256 128 64 64 and 0.535 s of pure entropy work.
 int Engine::batch_capacity(const mvhp_stream_params_t &p, int remaining) const
@@ -377,8 +378,12 @@ int Engine::planned_batch(int cap, int remaining, int batch_id) const
     const int share = (remaining + n_ctx - 1) / n_ctx;
     if (opts_.batch_pictures > 0) return std::max(1, std::min(cap, share));   // an explicit batch size is taken as given
     const int round = batch_id / n_ctx;                                         // batches each context has been given so far
-    const int ramp = round < 6 ? std::min(64 << round, cap) : cap;
-    const int taper = std::max(64, (int)((remaining * 0.35 + n_ctx - 1) / n_ctx));
+    // the ramp starts at, and the taper ends on, one picture per entropy thread: the threads finish such a batch together, and
+    // the last batch's upload + kernel + download (the tail nothing overlaps) is 6 ms for 16 full-HD pictures against 15 ms
+    // for 64.  Round 3: both were 64 -- a 64-picture job was ONE launch (36 ms; 26 ms in batches of 16), tools/e2e_ab.py.
+    const int unit = std::max(8, std::min(64, host_threads_ / n_ctx));
+    const int ramp = round < 10 ? std::min((long)unit << round, (long)cap) : cap;
+    const int taper = std::max(unit, (int)((remaining * 0.35 + n_ctx - 1) / n_ctx));
     return std::max(1, std::min(std::min(cap, ramp), std::min(share, taper)));
 }
 
