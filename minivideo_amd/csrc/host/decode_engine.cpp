@@ -348,7 +348,7 @@ int Engine::chunk_pictures(const mvhp_stream_params_t &p) const
 // next: what matters is that downloads start early and that the job's last download is short.  So batches RAMP UP from 64
 // pictures, doubling, to the cap (the download of batch k hides behind the entropy work of batch k+1 as long as batches
 // do not shrink faster than the link is quicker than the entropy stage), and TAPER at the end (each takes at most 35 %
-// of what is left per context, down to one picture per entropy thread): 16 32 64 128 256 512 364 236 154 100 65 42 27 18 16 16 2
+// of what is left per context, down to one picture per entropy thread): 16 32 64 128 256 512 364 236 154 100 65 42 27 18 16 18
 // for 2048 pictures on one context and 16 threads (round 2 started and ended on 64);
 // long jobs run most of their pictures in 1024-picture launches.  Modelled wall for 2048 x 1080p: 0.56 s against 0.63 s
 // with 1024 512 256 128 64 64 and 0.535 s of pure entropy work.
@@ -384,7 +384,9 @@ int Engine::planned_batch(int cap, int remaining, int batch_id) const
     const int unit = std::max(8, std::min(64, host_threads_ / n_ctx));
     const int ramp = round < 10 ? std::min((long)unit << round, (long)cap) : cap;
     const int taper = std::max(unit, (int)((remaining * 0.35 + n_ctx - 1) / n_ctx));
-    return std::max(1, std::min(std::min(cap, ramp), std::min(share, taper)));
+    int b = std::max(1, std::min(std::min(cap, ramp), std::min(share, taper)));
+    if (share - b > 0 && share - b < unit / 2 && share <= cap) b = share;   // (no two-picture batch behind the last full one)
+    return b;
 }
 
 bool Engine::ensure_devbuf(Ctx &c, DevBuf &b, const Batch &bt, std::string &err)
