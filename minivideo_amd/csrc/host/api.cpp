@@ -543,7 +543,9 @@ minivideo_EXPORT int minivideo_decode(MediaFile_t *m, const char *output_directo
         // over 6.3 MB, 7 ms; the run-length coder, 7 ms; against 3.7 ms): half as many writers as cores -- they sleep when
         // there is nothing to write, and the scheduler shares the cores between the two kinds of work.
         const int cores = mvengine::effective_cores();
-        int writers = (fmt == PICTURE_PNG || fmt == PICTURE_TGA) ? std::min(16, std::max(2, cores / 2)) : std::min(4, std::max(1, cores / 8));
+        int writers = (fmt == PICTURE_PNG || fmt == PICTURE_TGA) ? std::min(16, std::max(2, cores / 2))
+                      : (fmt == PICTURE_BMP)                         ? std::min(8, std::max(2, cores / 4))   // (4 ms: the B-G-R swap)
+                                                                     : std::min(4, std::max(1, cores / 8));
         if (const char *e = getenv("MINIVIDEO_WRITERS")) writers = std::max(0, std::min(16, atoi(e)));
         if (wanted < 4) writers = 0;
         if (writers > 0) sink.start(writers, eng);

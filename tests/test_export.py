@@ -69,3 +69,19 @@ def test_a_short_write_fails_the_writer(tool, fmt):
     if not os.path.exists("/dev/full"):
         pytest.skip("no /dev/full here")
     assert subprocess.run([tool, fmt, "64", "48", "1", "/dev/full"]).returncode == 1
+
+
+@pytest.mark.parametrize("w,h", [(1, 1), (5, 3), (6, 2), (7, 5), (11, 4), (21, 7), (112, 80), (1920, 8)])
+def test_bmp_rows_are_bottom_up_bgr(tool, tmp_path, w, h):
+    """stbi_write_bmp's layout (export.c:716-724); the R/B swap runs five pixels per SSSE3 shuffle with a scalar tail"""
+    out = tmp_path / "p.bmp"
+    seed = w * 17 + h
+    assert subprocess.run([tool, "bmp", str(w), str(h), str(seed), str(out)]).returncode == 0
+    d = out.read_bytes()
+    pad = (-w * 3) & 3
+    assert d[:2] == b"BM" and struct.unpack("<I", d[2:6])[0] == 54 + (w * 3 + pad) * h == len(d)
+    assert struct.unpack("<IIIHH", d[14:30]) == (40, w, h, 1, 24)
+    rows = np.frombuffer(d[54:], np.uint8).reshape(h, w * 3 + pad)
+    px = _pixels(w, h, seed).reshape(h, w, 3)
+    assert np.array_equal(rows[::-1, :w * 3].reshape(h, w, 3)[:, :, ::-1], px)
+    assert (rows[:, w * 3:] == 0).all()
