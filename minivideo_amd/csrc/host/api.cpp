@@ -540,7 +540,7 @@ minivideo_EXPORT int minivideo_decode(MediaFile_t *m, const char *output_directo
     sink.picture_number = picture_number;
     {   // file writers: two per sixteen cores keep up with the pipeline on the raw formats (0.5 ms of copying per picture);
         // the entropy threads need the rest.  PNG and TGA cost more CPU per picture than entropy decoding does (two checksums
-        // over 6.3 MB, 7 ms; the run-length coder, 7 ms; against 3.7 ms): half as many writers as cores -- they sleep when
+        // over 6.3 MB, 7 ms; the run-length coder, 5 ms; against 3.7 ms): half as many writers as cores -- they sleep when
         // there is nothing to write, and the scheduler shares the cores between the two kinds of work.
         const int cores = mvengine::effective_cores();
         int writers = (fmt == PICTURE_PNG || fmt == PICTURE_TGA) ? std::min(16, std::max(2, cores / 2))

@@ -156,8 +156,10 @@ int write_tga(const std::string &path, const uint8_t *rgb, int width, int height
                 }
             }
             if (diff) {
-                out.push_back((uint8_t)(len - 1));
-                for (int k = 0; k < len; ++k) { const uint8_t *p = begin + k * 3; out.push_back(p[2]); out.push_back(p[1]); out.push_back(p[0]); }
+                const size_t at = out.size();
+                out.resize(at + 1 + (size_t)len * 3);
+                out[at] = (uint8_t)(len - 1);
+                swap_rb(&out[at + 1], begin, (size_t)len);
             } else {
                 out.push_back((uint8_t)(len - 129));
                 out.push_back(begin[2]); out.push_back(begin[1]); out.push_back(begin[0]);

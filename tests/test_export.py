@@ -85,3 +85,28 @@ def test_bmp_rows_are_bottom_up_bgr(tool, tmp_path, w, h):
     px = _pixels(w, h, seed).reshape(h, w, 3)
     assert np.array_equal(rows[::-1, :w * 3].reshape(h, w, 3)[:, :, ::-1], px)
     assert (rows[:, w * 3:] == 0).all()
+
+
+def _flat_pixels(w, h, seed):
+    out = np.zeros((w * h, 3), np.uint8)
+    run = left = 0
+    for k in range(w * h):
+        if left == 0:
+            run += 1
+            left = 1 + (run * 37 + seed) % 200
+        for c in range(3):
+            out[k, c] = (((run * 2654435761) & 0xffffffff) + c * 97 + seed & 0xffffffff) >> 11 & 255
+        left -= 1
+    return out.reshape(-1)
+
+
+@pytest.mark.parametrize("w,h,flat", [(1, 1, 0), (7, 5, 0), (130, 3, 0), (300, 4, 1), (1920, 2, 0), (257, 3, 1), (640, 5, 1)])
+def test_tga_is_stb_rle(tool, tmp_path, w, h, flat):
+    """stbi_write_tga with RLE (export.c:726-733): byte for byte against the Python restatement the GPU CLI tests use, on noise
+    (raw packets, written through the vector R/B swap) and on runs of 1..200 equal pixels (run-length packets, 128-pixel splits)"""
+    from tests.test_gpu_api import _tga
+    out = tmp_path / "p.tga"
+    seed = w * 5 + h
+    assert subprocess.run([tool, "tga", str(w), str(h), str(seed), str(out)] + (["flat"] if flat else [])).returncode == 0
+    px = _flat_pixels(w, h, seed) if flat else _pixels(w, h, seed)
+    assert out.read_bytes() == _tga(px, w, h)
