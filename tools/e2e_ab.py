@@ -3,7 +3,7 @@
 the GPU box: one stream, one process, the configurations run in turn for several rounds, median / min / max of the
 wall time per configuration.  A single call varies by +-7 % from run to run on this pool; decisions need this.
 usage: e2e_ab.py [--pictures 2048] [--rounds 7] [--profile baseline] [--rgb 1] name:key=value,key=value ...
-   keys: batch (Engine batch_pictures), any MINIVIDEO_* environment variable (e.g. MINIVIDEO_IN_CHUNKS=8)"""
+   keys: batch (Engine batch_pictures), ctx (contexts; more than the devices = several contexts per device), any MINIVIDEO_* environment variable (e.g. MINIVIDEO_IN_CHUNKS=8)"""
 import argparse
 import ctypes as C
 import json
@@ -61,7 +61,7 @@ def main():
 
     for name, d in cfgs:
         apply_env(d)
-        engines[name] = Engine(contexts=1, batch_pictures=int(d.get("batch", 0)))
+        engines[name] = Engine(contexts=int(d.get("ctx", 1)), batch_pictures=int(d.get("batch", 0)))
         engines[name].decode(h, order, want_rgb=args.rgb)          # pools at working size
     for r in range(args.rounds):
         for name, d in (cfgs if r % 2 == 0 else cfgs[::-1]):
