@@ -334,7 +334,7 @@ MVHP_EXPORT void mvhp_engine_release_picture(mvhp_engine_t *e, int seq);
  * same half take about twice as long per pass as two windows in different halves. */
 MVHP_EXPORT int  mvhp_probe_pair(int device, void *d_a, void *d_b, size_t bytes, int reps, float *ms_per_pass);
 /* `count` (<= 8) device buffers of at least bytes[i] inside ONE allocation (arena_bytes = 0: what is free less 24 GB, at most
- * 200 GB), placed -- as far as the arena shows several groups -- so that every buffer lies in a group of its own, the largest
+ * 200 GB or MVHP_PLACED_ARENA_GB from the environment), placed -- as far as the arena shows several groups -- so that every buffer lies in a group of its own, the largest
  * choosing first: records, planes and RGB of a batch in three different groups is the fastest placement there is
  * (tools/placement_predict.py).  For long-lived batch buffers: the large allocation takes seconds (the driver clears it).
  * groups_of[i] (may be NULL): group of buffer i, -1 = straddles; *groups_found (may be NULL): groups seen in the arena.

@@ -75,6 +75,18 @@ struct Arena {
 };
 constexpr size_t kBlock = (size_t)4 << 30, kWindow = (size_t)1 << 30;
 
+// The arena a caller gets when it names no size: 200 GB -- more blocks to choose from is a better placement -- unless
+// MVHP_PLACED_ARENA_GB says otherwise (the test suite asks for 48: memory a process has written is wiped when the process
+// releases it, and the NEXT process's first device allocations wait for that, 3 s behind a 200-GB arena).
+static size_t default_arena_cap()
+{
+    if (const char *e = getenv("MVHP_PLACED_ARENA_GB")) {
+        const long gb = atol(e);
+        if (gb >= 8 && gb <= 256) return (size_t)gb << 30;
+    }
+    return (size_t)200 << 30;
+}
+
 // a probe that fails makes every later comparison meaningless: remembered in `failed`, checked before anything is placed
 struct Probe {
     int device;
@@ -109,7 +121,7 @@ MVHP_EXPORT int mvhp_placed_alloc(int device, int count, const size_t *bytes, si
     }
     if (arena_bytes == 0) {
         const size_t reserve = (size_t)24 << 30;
-        arena_bytes = fr > reserve ? std::min(fr - reserve, (size_t)200 << 30) : 0;
+        arena_bytes = fr > reserve ? std::min(fr - reserve, default_arena_cap()) : 0;
     }
     arena_bytes = arena_bytes / kBlock * kBlock;
     if (arena_bytes < need) return MVHP_FAILURE;
@@ -278,7 +290,7 @@ MVHP_EXPORT int mvhp_placed_alloc_sets(int device, int sets, int count, const si
     if (own.size() > 4) return MVHP_FAILURE;
     if (arena_bytes == 0) {
         const size_t reserve = (size_t)24 << 30;
-        arena_bytes = fr > reserve ? std::min(fr - reserve, (size_t)200 << 30) : 0;
+        arena_bytes = fr > reserve ? std::min(fr - reserve, default_arena_cap()) : 0;
     }
     arena_bytes = arena_bytes / kBlock * kBlock;
     if (arena_bytes < need) return MVHP_FAILURE;
