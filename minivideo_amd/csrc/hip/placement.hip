@@ -76,8 +76,8 @@ struct Arena {
 constexpr size_t kBlock = (size_t)4 << 30, kWindow = (size_t)1 << 30;
 
 // The arena a caller gets when it names no size: 200 GB -- more blocks to choose from is a better placement -- unless
-// MVHP_PLACED_ARENA_GB says otherwise (the test suite asks for 48: memory a process has written is wiped when the process
-// releases it, and the NEXT process's first device allocations wait for that, 3 s behind a 200-GB arena).
+// MVHP_PLACED_ARENA_GB says otherwise (memory a process has held is wiped when it is released, in the background, about 3 s for 200 GB,
+// and device allocations made meanwhile -- by this or the next process -- wait for it).
 static size_t default_arena_cap()
 {
     if (const char *e = getenv("MVHP_PLACED_ARENA_GB")) {

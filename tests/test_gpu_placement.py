@@ -12,13 +12,6 @@ pytestmark = pytest.mark.gpu
 GB = 1 << 30
 
 
-@pytest.fixture(autouse=True)
-def _modest_default_arena(monkeypatch):
-    """where a test lets the library choose the arena size it gets 48 GB instead of 200: what this process writes is wiped when
-    it exits, and the next process on the device (the driver's smoke() and bench.py) would wait seconds for its first allocations"""
-    monkeypatch.setenv("MVHP_PLACED_ARENA_GB", "48")
-
-
 def _hip():
     h = C.CDLL("libamdhip64.so")
     h.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
