@@ -1,7 +1,8 @@
 """CPU: the decode engine's threading (csrc/host/decode_engine.cpp) built without HIP against a stub device table and
 run under ThreadSanitizer (tools/engine_harness.cpp): in-order delivery through chunks / batches / several contexts,
 `wanted` caps the entropy work (one thumbnail = one picture decoded), a failed batch is re-queued once to
-another context, a broken picture arrives as a failure in its place.  No reconstruction happens here --
+another context, a broken picture arrives as a failure in its place; pictures a sink keeps and other threads
+release; and the public API (minivideo_open / parse / decode) with its file-writer pool.  No reconstruction happens here --
 the stub stamps outputs with a checksum of the records it was handed."""
 import os
 import subprocess
@@ -14,7 +15,7 @@ from minivideo_amd import gen
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HOST = os.path.join(ROOT, "minivideo_amd", "csrc", "host")
 SRC = [os.path.join(ROOT, "tools", "engine_harness.cpp")] + [os.path.join(HOST, f) for f in (
-    "decode_engine.cpp", "stream_abi.cpp", "h264_frontend.cpp", "h264_cabac.cpp", "mp4_demux.cpp")]
+    "decode_engine.cpp", "stream_abi.cpp", "h264_frontend.cpp", "h264_cabac.cpp", "mp4_demux.cpp", "api.cpp", "export.cpp")]
 
 
 def _build(tmp_path, sanitize):

@@ -8,6 +8,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <unistd.h>
 
 #include <atomic>
 #include <chrono>
@@ -19,6 +20,7 @@
 #include <vector>
 
 #include "decode_engine.h"
+#include "minivideo.h"
 #include "stream_internal.h"
 
 // ---- the pieces of the C-ABI the engine uses that live in the HIP translation unit of the product ----
@@ -26,6 +28,7 @@ extern "C" {
 size_t mvhp_packed_frame_bytes(const mvhp_stream_params_t *p) { return p ? (size_t)p->width_mbs * p->height_mbs * MVHP_MB_BYTES : 0; }
 size_t mvhp_yuv_frame_bytes(const mvhp_stream_params_t *p) { return p ? (size_t)p->width_mbs * p->height_mbs * 384 : 0; }
 size_t mvhp_rgb_frame_bytes(const mvhp_stream_params_t *p) { return p ? (size_t)p->width_mbs * p->height_mbs * 768 : 0; }
+int mvhp_device_count(void) { return 1; }
 }
 
 namespace mvengine {
@@ -350,6 +353,48 @@ int main(int argc, char **argv)
         mvhp_engine_destroy(e);
         printf("%-28s ok=%d failed=%d issued=%u\n", "broken picture", st2.ok, st2.failed, st.pictures_issued);
         EXPECT(st2.bad == 0 && st2.failed == 1 && st2.ok == wanted);
+    }
+    {   // the PUBLIC API on the stub device: minivideo_open / parse / decode with the file-writer pool (the sink keeps pictures,
+        // writer threads write and release them) -- under the sanitizers this is the check of that hand-over.  The stub's
+        // "pictures" carry the checksum of their records in the first eight bytes, which is what the files must start with.
+        char tmpl[] = "/tmp/mvharness_XXXXXX";
+        const char *dir = mkdtemp(tmpl);
+        EXPECT(dir != nullptr);
+        char cwd[4096];
+        EXPECT(getcwd(cwd, sizeof(cwd)) != nullptr);
+        std::string in = argv[1];
+        if (in[0] != '/') in = std::string(cwd) + "/" + in;
+        EXPECT(dir && chdir(dir) == 0);
+        for (const char *writers : {"3", "0"}) {
+            setenv("MINIVIDEO_WRITERS", writers, 1);
+            MediaFile_t *m = nullptr;
+            EXPECT(minivideo_open(in.c_str(), &m) == SUCCESS);
+            EXPECT(m && minivideo_parse(m, false, true, false) == SUCCESS);
+            EXPECT(m && minivideo_decode(m, ".", PICTURE_YUV420, 75, n_idr, PICTURE_UNFILTERED) == SUCCESS);
+            int files = 0, good = 0;
+            for (int k = 0; k < n_idr; k++) {
+                const std::string name = std::string(m->file_name) + "_" + std::to_string(k) + ".yuv";
+                FILE *g = fopen(name.c_str(), "rb");
+                if (!g) continue;
+                files++;
+                uint64_t got = 0;
+                std::vector<uint8_t> packed;
+                mvhp_stream_params_t p;
+                if (fread(&got, 1, 8, g) == 8 && mvhp_stream_params(&s, k, &p) == MVHP_SUCCESS) {
+                    packed.resize(mvhp_packed_frame_bytes(&p));
+                    std::string er;
+                    if (s.decode_packed(k, packed.data(), packed.size(), er) == h264::RC_SUCCESS && got == checksum(packed.data(), packed.size())) good++;
+                }
+                fclose(g);
+                remove(name.c_str());
+            }
+            printf("%-28s writers=%s files=%d of %d, right picture in %d\n", "public API", writers, files, n_idr, good);
+            EXPECT(files == n_idr && good == n_idr);
+            EXPECT(minivideo_close(&m) == SUCCESS);
+        }
+        unsetenv("MINIVIDEO_WRITERS");
+        EXPECT(chdir(cwd) == 0);
+        rmdir(dir);
     }
     EXPECT(g_live_ctx == 0 && g_dev_allocs == 0);
     printf(failures ? "HARNESS FAILED (%d)\n" : "HARNESS OK\n", failures);
