@@ -253,6 +253,13 @@ MVHP_EXPORT int  mvhp_set_waves_per_picture(mvhp_ctx_t *ctx, int waves);
 #define MVHP_LAYOUT_ROWS 1
 #define MVHP_LAYOUT_QUAD 2
 #define MVHP_LAYOUT_OCT  3
+/* The "wide" forms spread ONE picture (one group of four) over several workgroups -- bands of macroblock rows on different
+ * CUs, the rows between two bands handed over through global memory -- so that a handful of pictures fills the chip:
+ * MVHP_LAYOUT_WIDE = the one-picture kernel in bands (1 .. ~64 pictures; also every small batch with slices / scaling
+ * matrices), MVHP_LAYOUT_QUAD_WIDE = the four-picture kernel in bands (up to ~1024 pictures). */
+#define MVHP_LAYOUT_WIDE      4
+#define MVHP_LAYOUT_QUAD_WIDE 5
+#define MVHP_LAYOUT_COUNT     6
 MVHP_EXPORT int  mvhp_set_layout(mvhp_ctx_t *ctx, int layout);
 
 /* ---------------------------------------------------------------------------

@@ -58,6 +58,15 @@ struct mvhp_ctx {
     int          n_cus;
     size_t       max_lds;
     int          last_layout, last_waves;   // what the last reconstruction launch used
+    // wide launches (MVHP_LAYOUT_WIDE / QUAD_WIDE): ticket counter, seam granules, the tag of the last launch.  One set per
+    // context: two wide launches of one context never overlap (a launch on another stream waits for the previous one).
+    uint32_t    *d_ticket;
+    uint32_t     ticket_base;               // value of *d_ticket once every launch issued so far has run
+    uint32_t     wide_epoch;
+    void        *d_seam;
+    size_t       d_seam_bytes;
+    hipEvent_t   wide_done;                 // recorded behind the last wide launch
+    hipStream_t  wide_stream;               // the stream it ran on
     // staging for the host convenience path
     void        *d_packed;
     size_t       d_packed_bytes;
@@ -115,16 +124,20 @@ MVHP_EXPORT int mvhp_create(int device, mvhp_ctx_t **out)
         if (!strcmp(e, "rows")) c->layout = MVHP_LAYOUT_ROWS;
         else if (!strcmp(e, "quad")) c->layout = MVHP_LAYOUT_QUAD;
         else if (!strcmp(e, "oct")) c->layout = MVHP_LAYOUT_OCT;
+        else if (!strcmp(e, "wide")) c->layout = MVHP_LAYOUT_WIDE;
+        else if (!strcmp(e, "quad_wide")) c->layout = MVHP_LAYOUT_QUAD_WIDE;
     }
     c->n_cus = prop.multiProcessorCount;
     c->max_lds = prop.maxSharedMemoryPerMultiProcessor ? prop.maxSharedMemoryPerMultiProcessor : 65536;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipMalloc(&c->d_err, sizeof(uint32_t)) != hipSuccess ||
-        hipMemset(c->d_err, 0, sizeof(uint32_t)) != hipSuccess) {
+        hipMalloc(&c->d_err, 2 * sizeof(uint32_t)) != hipSuccess ||
+        hipMemset(c->d_err, 0, 2 * sizeof(uint32_t)) != hipSuccess ||
+        hipEventCreateWithFlags(&c->wide_done, hipEventDisableTiming) != hipSuccess) {
         set_err("context allocation failed on device %d", device);
         delete c;
         return MVHP_FAILURE;
     }
+    c->d_ticket = c->d_err + 1;   // (the error word and the ticket counter share one small allocation)
     *out = c;
     return MVHP_SUCCESS;
 }
@@ -138,6 +151,8 @@ MVHP_EXPORT void mvhp_destroy(mvhp_ctx_t *c)
     if (c->d_yuv) hipFree(c->d_yuv);
     if (c->d_rgb) hipFree(c->d_rgb);
     if (c->d_err) hipFree(c->d_err);
+    if (c->d_seam) hipFree(c->d_seam);
+    if (c->wide_done) hipEventDestroy(c->wide_done);
     hipStreamDestroy(c->stream);
     delete c;
 }
@@ -151,7 +166,7 @@ MVHP_EXPORT int mvhp_set_waves_per_picture(mvhp_ctx_t *c, int waves)
 
 MVHP_EXPORT int mvhp_set_layout(mvhp_ctx_t *c, int layout)
 {
-    if (!c || layout < MVHP_LAYOUT_AUTO || layout > MVHP_LAYOUT_OCT) return MVHP_FAILURE;
+    if (!c || layout < MVHP_LAYOUT_AUTO || layout >= MVHP_LAYOUT_COUNT) return MVHP_FAILURE;
     c->layout = layout;
     return MVHP_SUCCESS;
 }
@@ -178,12 +193,16 @@ MVHP_EXPORT int mvhp_set_fused_color(mvhp_ctx_t *c, int on)
     return MVHP_SUCCESS;
 }
 
+// largest batch the one-picture kernel reconstructs in bands (MVHP_LAYOUT_WIDE) rather than one workgroup per picture
+static int wide_rows_max(const mvhp_ctx *c) { return c->n_cus / 2; }
+
 static int pick_layout(const mvhp_ctx *c, const mvhp_stream_params_t *p, int n_frames)
 {
     int layout = c->layout;
     // pictures of several slices and scaling matrices (MVHP_STREAM_SPEC streams): the one-picture kernel,
     // where a neighbour's availability is a per-wavefront scalar and LevelScale is a table in LDS -- whatever was asked for
-    if (p->flags & (MVHP_PARAM_SLICES | MVHP_PARAM_SCALING)) return MVHP_LAYOUT_ROWS;
+    if (p->flags & (MVHP_PARAM_SLICES | MVHP_PARAM_SCALING))
+        return (layout == MVHP_LAYOUT_ROWS || (layout != MVHP_LAYOUT_WIDE && n_frames > wide_rows_max(c))) ? MVHP_LAYOUT_ROWS : MVHP_LAYOUT_WIDE;
     if (layout == MVHP_LAYOUT_AUTO) {
         // speed only.  A launch is a number of "rounds" of one workgroup per CU (the batch kernels fill a CU with one
         // workgroup); measured on 1080p, in units of one full round of the four-picture kernel (5.4 ms for 4 * CUs
@@ -201,6 +220,8 @@ static int pick_layout(const mvhp_ctx *c, const mvhp_stream_params_t *p, int n_f
         const bool oct_fits = mvhp::recon_oct_lds_bytes((int)p->width_mbs, 8) <= c->max_lds;   // with six waves it loses to quad
         const double t_oct = oct_fits ? rounds(8 * cus, 1.48, 1.85) : 1e30;
         layout = (t_rows <= t_quad && t_rows <= t_oct) ? MVHP_LAYOUT_ROWS : (t_oct < t_quad ? MVHP_LAYOUT_OCT : MVHP_LAYOUT_QUAD);
+        // few pictures: spread each over several workgroups
+        if (layout == MVHP_LAYOUT_ROWS && n_frames <= wide_rows_max(c)) layout = MVHP_LAYOUT_WIDE;
     }
     // the batch kernels address a workgroup's pictures with 32-bit offsets and keep one line buffer per picture in LDS
     const size_t mbs = (size_t)p->width_mbs * p->height_mbs;
@@ -213,6 +234,7 @@ static int pick_layout(const mvhp_ctx *c, const mvhp_stream_params_t *p, int n_f
 static int pick_waves(const mvhp_ctx *c, const mvhp_stream_params_t *p, int n_frames, int layout)
 {
     int nw = c->waves;
+    if (layout == MVHP_LAYOUT_WIDE) return 4;   // rows per band (built for 4: the finest grain, 17 bands per 1080p picture)
     if (layout == MVHP_LAYOUT_OCT) {
         // speed only: built for 4, 6 and 8 waves; one workgroup per CU (LDS)
         static const int opts[3] = {8, 6, 4};
@@ -253,6 +275,37 @@ static int pick_waves(const mvhp_ctx *c, const mvhp_stream_params_t *p, int n_fr
     return nw;
 }
 
+// Everything a wide launch needs besides the batch: seam granules for its band boundaries (grown on demand, zeroed once: a
+// granule counts when its tag equals the launch's epoch, and epochs never repeat), the ticket base, ordering behind the
+// context's previous wide launch when that ran on another stream (they share the counter and the seams).
+static int wide_prepare(mvhp_ctx *c, mvhp::ReconArgs &a, size_t seam_bytes, uint32_t units, hipStream_t st)
+{
+    if (c->wide_stream && c->wide_stream != st) HIP_TRY(hipStreamWaitEvent(st, c->wide_done, 0));
+    if (seam_bytes > c->d_seam_bytes) {
+        if (c->d_seam) {
+            HIP_TRY(hipEventSynchronize(c->wide_done));   // (the previous wide launch may still read the old one)
+            HIP_TRY(hipFree(c->d_seam));
+            c->d_seam = nullptr;
+            c->d_seam_bytes = 0;
+        }
+        const size_t want = seam_bytes + seam_bytes / 4;
+        HIP_TRY(hipMalloc(&c->d_seam, want));
+        c->d_seam_bytes = want;
+        HIP_TRY(hipMemsetAsync(c->d_seam, 0, want, st));
+    }
+    if (++c->wide_epoch == 0) {   // 2^32 launches later: tags would repeat
+        if (c->d_seam) HIP_TRY(hipMemsetAsync(c->d_seam, 0, c->d_seam_bytes, st));
+        c->wide_epoch = 1;
+    }
+    a.wide_ticket = c->d_ticket;
+    a.wide_base = c->ticket_base;
+    a.wide_epoch = c->wide_epoch;
+    a.seam = (unsigned long long *)c->d_seam;
+    (void)units;
+    c->wide_stream = st;
+    return MVHP_SUCCESS;
+}
+
 static int launch_all(mvhp_ctx *c, const mvhp_stream_params_t *p, const void *d_packed, int n_frames,
                       uint8_t *d_yuv, uint8_t *d_rgb, hipStream_t st, bool recon, bool color)
 {
@@ -276,11 +329,25 @@ static int launch_all(mvhp_ctx *c, const mvhp_stream_params_t *p, const void *d_
         } else {
             memset(a.weights, 16, sizeof(a.weights));
         }
+        a.wide_ticket = nullptr;
+        a.wide_base = a.wide_epoch = 0;
+        a.seam = nullptr;
         const int layout = pick_layout(c, p, n_frames);
         const int nw = pick_waves(c, p, n_frames, layout);
         c->last_layout = layout;
         c->last_waves = nw;
-        if (layout == MVHP_LAYOUT_OCT) {
+        if (layout == MVHP_LAYOUT_WIDE) {
+            if (mvhp::recon_lds_bytes(a.width_mbs, nw) > c->max_lds) {
+                set_err("picture too wide for the LDS line buffer (%u macroblocks)", p->width_mbs);
+                return MVHP_UNSUPPORTED;
+            }
+            const int rc = wide_prepare(c, a, mvhp::recon_wide_seam_bytes(a.width_mbs, a.height_mbs, n_frames, nw),
+                                        (uint32_t)n_frames * (uint32_t)((a.height_mbs + nw - 1) / nw), st);
+            if (rc != MVHP_SUCCESS) return rc;
+            HIP_TRY(mvhp::launch_recon_wide(a, n_frames, nw, st));
+            c->ticket_base += (uint32_t)n_frames * (uint32_t)((a.height_mbs + nw - 1) / nw);   // every workgroup takes one ticket
+            HIP_TRY(hipEventRecord(c->wide_done, st));
+        } else if (layout == MVHP_LAYOUT_OCT) {
             HIP_TRY(mvhp::launch_recon_oct(a, nw, st));
         } else if (layout == MVHP_LAYOUT_QUAD) {
             HIP_TRY(mvhp::launch_recon_quad(a, nw, st));

@@ -20,7 +20,25 @@ struct ReconArgs {
     int            slices;          // MVHP_PARAM_SLICES: mvhp_mb_header_t::unavail is honoured
     int            scaling;         // MVHP_PARAM_SCALING: weights[] below instead of Flat_4x4_16 / Flat_8x8_16
     uint8_t        weights[112];    // scaling4[3][16] | scaling8[64], raster order
+    // Wide launches (launch_recon_wide / launch_recon_quad_wide): a picture's macroblock rows are spread over several
+    // workgroups ("bands" of NW consecutive rows), so that a handful of pictures fills the chip.
+    uint32_t      *wide_ticket;     // device counter; a workgroup's unit (picture, band) = atomicAdd(ticket, 1) - wide_base:
+                                    // units are taken in the order workgroups START, so the band a workgroup waits for is
+                                    // always held by a workgroup that is already running (no assumption on dispatch order)
+    uint32_t       wide_base;       // value of *wide_ticket when this launch starts (the counter is never reset)
+    uint32_t       wide_epoch;      // tag of this launch's seam granules (never 0, differs from every tag left in `seam`)
+    unsigned long long *seam;       // [picture][seam = band boundary][macroblock column][8] granules {bottom-row dword, tag}:
+                                    // the last row of a band hands its bottom samples (16 luma + 8 Cb + 8 Cr per column) to the
+                                    // first row of the next band, which runs on another CU
 };
+
+// granules per macroblock column of a seam, and their size
+constexpr int SEAM_GRANULES = 8;
+inline size_t recon_wide_seam_bytes(int width_mbs, int height_mbs, int n_frames, int nw)
+{
+    const int bands = (height_mbs + nw - 1) / nw;
+    return (size_t)n_frames * (size_t)(bands > 1 ? bands - 1 : 0) * width_mbs * SEAM_GRANULES * sizeof(unsigned long long);
+}
 
 struct ExpandArgs {
     const uint8_t *compact;  // n_pictures compact pictures, `stride` bytes apart
@@ -37,6 +55,8 @@ struct ColorArgs {
 
 size_t     recon_lds_bytes(int width_mbs, int nw);
 hipError_t launch_recon(const ReconArgs &a, int n_frames, int nw, hipStream_t stream);
+// the same kernel with a picture's rows in bands of `nw` (4) over several workgroups (wide_* and seam of ReconArgs set)
+hipError_t launch_recon_wide(const ReconArgs &a, int n_frames, int nw, hipStream_t stream);
 // four pictures per workgroup, 16 lanes per picture (recon_quad.hip)
 size_t     recon_quad_lds_bytes(int width_mbs, int nw);
 hipError_t launch_recon_quad(const ReconArgs &a, int nw, hipStream_t stream);

@@ -48,7 +48,8 @@ struct __attribute__((aligned(16))) WaveLds {
 struct __attribute__((aligned(16))) BlockLds {
     int     progress[16];  // macroblocks completed by wave w (monotonic over its rows)
     int     abort_flag;
-    int     pad[3];
+    int     unit;          // WIDE: this workgroup's ticket (picture * bands + band)
+    int     pad[2];
     int     ls4[18];       // LevelScale4x4 classes, 16*normAdjust (h264.c:427-435)
     int     ls8[36];       // LevelScale8x8 classes (h264.c:438-446)
     uint8_t cls8[64];      // 8x8 position -> class
@@ -507,7 +508,17 @@ __device__ __forceinline__ void predict_chroma(WaveLds &W, int lane, int mode, b
 // ---------------------------------------------------------------------------
 // EXT: pictures of several slices and / or scaling matrices (MVHP_PARAM_SLICES, MVHP_PARAM_SCALING: MVHP_STREAM_SPEC streams,
 // SURVEY 8f row f4) -- an instantiation of its own; the ordinary one is the round-2 kernel plus the I_PCM copy.
-template <int NW, bool EXT>
+// WIDE: a workgroup reconstructs ONE BAND of a picture -- NW consecutive macroblock rows, one per wavefront, a single pass --
+// and a picture's bands run on different CUs ("grid = F x PicHeightInMbs wavefronts"): sixteen 1080p
+// pictures fill the 256 CUs where the one-workgroup-per-picture form needs 256.  Inside a band nothing changes (progress
+// counters and line buffer in LDS).  Across a band boundary ("seam") the bottom samples of the upper band's last row travel
+// through global memory as 8-byte granules {dword of samples, tag of this launch}, each written by ONE agent-scope (sc1,
+// write-through) store and polled with agent-scope loads: a granule is there or it is not, so there is no separate flag,
+// no fence and no wait on the producer's side (MI355X_MICROARCH "handoff-1to1": data-tagged granules).  The consumer asks for
+// the columns of the NEXT macroblock pair before it starts on this one, so in the steady state the hand-off's latency hides
+// behind a pair's work.  Units (picture, band) are handed out by a ticket counter in the order workgroups start: the band
+// above is always held by a workgroup that is already running, whatever order the hardware dispatches in.
+template <int NW, bool EXT, bool WIDE>
 __global__ __launch_bounds__(NW * 64) void recon_rows_kernel(ReconArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -520,7 +531,7 @@ __global__ __launch_bounds__(NW * 64) void recon_rows_kernel(ReconArgs a)
     const int lane_c = threadIdx.x & 63;
     const int lane = lane_c;
     WaveLds &Wv = *reinterpret_cast<WaveLds *>(line_cr + W * 8 + (size_t)wave * sizeof(WaveLds));
-    const int frame = blockIdx.x;
+    if (WIDE && threadIdx.x == 0) B.unit = (int)(atomicAdd(a.wide_ticket, 1u) - a.wide_base);
 
     // ---- one-time table setup ----
     for (int i = threadIdx.x; i < 18; i += NW * 64) B.ls4[i] = 16 * c_v4x4[i];
@@ -544,6 +555,21 @@ __global__ __launch_bounds__(NW * 64) void recon_rows_kernel(ReconArgs a)
     if (threadIdx.x < 16) B.progress[threadIdx.x] = 0;
     if (threadIdx.x == 16) B.abort_flag = 0;
     __syncthreads();
+
+    const int bands = (H + NW - 1) / NW;
+    const int unit = WIDE ? __builtin_amdgcn_readfirstlane(B.unit) : 0;
+    const int frame = WIDE ? unit / bands : (int)blockIdx.x;
+    const int band = WIDE ? unit - frame * bands : 0;
+    if (WIDE && (unsigned)frame >= (unsigned)a.n_frames) return;   // (cannot happen: the grid has n_frames * bands workgroups)
+    const int row_first = WIDE ? band * NW : 0;
+    const int row_end = WIDE ? min(H, row_first + NW) : H;
+    // seams: the first row of a band below the first takes its top neighbours from the seam above; the last row of a band
+    // above the last one feeds the seam below
+    const bool seam_in = WIDE && wave == 0 && band > 0;
+    const bool seam_out = WIDE && wave == NW - 1 && row_first + NW < H;
+    const unsigned long long *seam_rd = seam_in ? a.seam + (size_t)(frame * (bands - 1) + band - 1) * W * SEAM_GRANULES : nullptr;
+    unsigned long long *seam_wr = seam_out ? a.seam + (size_t)(frame * (bands - 1) + band) * W * SEAM_GRANULES : nullptr;
+    const unsigned long long seam_tag = (unsigned long long)a.wide_epoch << 32;
 
     const uint8_t *fpacked = a.packed + (size_t)frame * W * H * MVHP_MB_BYTES;
     uint8_t *fy = a.yuv + (size_t)frame * W * H * 384;
@@ -588,7 +614,7 @@ __global__ __launch_bounds__(NW * 64) void recon_rows_kernel(ReconArgs a)
     auto prefetch = [&](int prow, int px, int lane_c) {
         pA = make_int4(0, 0, 0, 0);
         pB = make_int4(0, 0, 0, 0);
-        if (prow >= H) return;
+        if (prow >= row_end) return;
         const uint8_t *rec0 = fpacked + (size_t)(prow * W + px) * MVHP_MB_BYTES;
         const bool two = (px + 1) < W;
         const uint8_t *src = nullptr;
@@ -601,11 +627,12 @@ __global__ __launch_bounds__(NW * 64) void recon_rows_kernel(ReconArgs a)
             if (lane_c < 48) pB = *reinterpret_cast<const int4 *>(src + 16);
         }
     };
-    prefetch(wave, 0, lane_c);
+    prefetch(row_first + wave, 0, lane_c);
 
     int done = 0; // macroblocks completed by this wave
-    for (int row = wave; row < H; row += NW) {
-        const int pass = row / NW;
+    unsigned long long seam_pend = 0;   // WIDE, seam_in: the granule this lane requested for the next macroblock pair
+    for (int row = row_first + wave; row < row_end; row += NW) {
+        const int pass = WIDE ? 0 : row / NW;
         const int up_base = ((wave == 0) ? (pass - 1) : pass) * W; // MBs the upper wave finished before its row (row-1)
         const bool Bv = row > 0;
         for (int mbx0 = 0; mbx0 < W; mbx0 += 2) {
@@ -613,9 +640,40 @@ __global__ __launch_bounds__(NW * 64) void recon_rows_kernel(ReconArgs a)
             int lane_p = lane_c;
             asm volatile("" : "+v"(lane_p)); // see the per-macroblock copy below
             const int4 cA = pA, cB = pB;
+            if (WIDE && seam_in) {
+                // This pair reads columns <= mbx0 + 2 of the row above.  The first pair of a row asks for columns 0..2 now;
+                // every later pair finds (mbx0 + 1, mbx0 + 2) requested one pair ago.  Lane l: column c0 + (l >> 3), granule
+                // l & 7 (0-3 luma dwords, 4-5 Cb, 6-7 Cr).  Then the request for the next pair, (mbx0 + 3, mbx0 + 4).
+                const int c0 = mbx0 ? mbx0 + 1 : 0, ncol = mbx0 ? 2 : 3;
+                const int col = c0 + (lane_p >> 3), g = lane_p & 7;
+                const bool act = (lane_p < ncol * 8) && (col < W);
+                const unsigned long long *src = seam_rd + (size_t)(act ? col : 0) * SEAM_GRANULES + g;
+                unsigned long long v = seam_pend;
+                if (mbx0 == 0) v = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                int spins = 0;
+                while (__builtin_amdgcn_ballot_w64(act && (v >> 32) != (unsigned long long)a.wide_epoch) != 0) {
+                    __builtin_amdgcn_s_sleep(2);
+                    // bounded: 2^20 polls of ~1 us; a failure anywhere in the launch (error word) ends every wait
+                    bool stop = ++spins > (1 << 20) || __hip_atomic_load(&B.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (!stop && (spins & 255) == 0) stop = __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+                    if (stop) {
+                        if (lane_p == 0) { __hip_atomic_store(&B.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); atomicOr(a.err, 1u); }
+                        return;
+                    }
+                    v = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                if (act) {
+                    uint8_t *dst = (g < 4) ? &line_y[col * 16 + g * 4] : (g < 6) ? &line_cb[col * 8 + (g - 4) * 4] : &line_cr[col * 8 + (g - 6) * 4];
+                    *reinterpret_cast<uint32_t *>(dst) = (uint32_t)v;
+                }
+                const int ncolumn = mbx0 + 3 + (lane_p >> 3);
+                if (lane_p < 16 && ncolumn < W)
+                    seam_pend = __hip_atomic_load(seam_rd + (size_t)ncolumn * SEAM_GRANULES + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                WAVE_SYNC();
+            }
             {   // next pair of this wave: same row, or the first pair of its next row
                 int nrow = row, nx = mbx0 + 2;
-                if (nx >= W) { nrow = row + NW; nx = 0; }
+                if (nx >= W) { nrow = row + NW; nx = 0; }   // (WIDE: a wave has one row -- prefetch() answers zeros beyond row_end)
                 prefetch(nrow, nx, lane_p);
             }
             // headers: wave-uniform -> scalars (v_readlane from the header lanes)
@@ -678,7 +736,7 @@ __global__ __launch_bounds__(NW * 64) void recon_rows_kernel(ReconArgs a)
 
             // ---- wait for the row above: needs columns <= min(mbx+1, W-1) ----
             if (BvG) {
-                const int need = up_base + min(mbx + 2, W);
+                const int need = (WIDE && seam_in) ? 0 : up_base + min(mbx + 2, W);   // (seam_in: the pair's columns are in the line buffer)
                 int spins = 0;
                 while (__hip_atomic_load(&B.progress[up_wave], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < need) {
                     __builtin_amdgcn_s_sleep(1);
@@ -784,6 +842,8 @@ __global__ __launch_bounds__(NW * 64) void recon_rows_kernel(ReconArgs a)
             WAVE_SYNC();
             if (keep_act) { *keep_dst = (uint8_t)keep; *keep_dst2 = (uint8_t)keep; }
             if (bot_act) *reinterpret_cast<uint32_t *>(bot_dst + mbx * bot_mul) = bot;
+            if (WIDE && seam_out && bot_act)   // the same eight dwords, tagged, to the band below (one write-through store per granule)
+                __hip_atomic_store(seam_wr + (size_t)mbx * SEAM_GRANULES + (lane - 48), seam_tag | bot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             // ---- publish ----
             done++;
             // LDS operations of one wave complete in order; the explicit wait makes the line-buffer
@@ -843,13 +903,24 @@ size_t recon_lds_bytes(int width_mbs, int nw)
     return sizeof(BlockLds) + (size_t)width_mbs * 32 + (size_t)nw * sizeof(WaveLds);
 }
 
-template <int NW, bool EXT>
-static hipError_t launch_rows_one(const ReconArgs &a, int n_frames, size_t lds, hipStream_t stream)
+template <int NW, bool EXT, bool WIDE = false>
+static hipError_t launch_rows_one(const ReconArgs &a, int n_groups, size_t lds, hipStream_t stream)
 {
-    hipError_t e = hipFuncSetAttribute((const void *)recon_rows_kernel<NW, EXT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute((const void *)recon_rows_kernel<NW, EXT, WIDE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((recon_rows_kernel<NW, EXT>), dim3(n_frames), dim3(NW * 64), lds, stream, a);
+    hipLaunchKernelGGL((recon_rows_kernel<NW, EXT, WIDE>), dim3(n_groups), dim3(NW * 64), lds, stream, a);
     return hipGetLastError();
+}
+
+// one workgroup per (picture, band of nw rows); a.wide_ticket / wide_base / wide_epoch / seam set by the caller
+hipError_t launch_recon_wide(const ReconArgs &a, int n_frames, int nw, hipStream_t stream)
+{
+    if (nw != 4 || !a.wide_ticket || !a.wide_epoch) return hipErrorInvalidValue;
+    const int bands = (a.height_mbs + nw - 1) / nw;
+    if (bands > 1 && !a.seam) return hipErrorInvalidValue;
+    const size_t lds = recon_lds_bytes(a.width_mbs, nw);
+    const bool ext = a.slices || a.scaling;
+    return ext ? launch_rows_one<4, true, true>(a, n_frames * bands, lds, stream) : launch_rows_one<4, false, true>(a, n_frames * bands, lds, stream);
 }
 
 hipError_t launch_recon(const ReconArgs &a, int n_frames, int nw, hipStream_t stream)

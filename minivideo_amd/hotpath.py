@@ -12,6 +12,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
 
+LAYOUTS = ("auto", "rows", "quad", "oct", "wide", "quad_wide")   # MVHP_LAYOUT_*
+
+
 class MiniVideoError(RuntimeError):
     pass
 
@@ -137,10 +140,11 @@ class HotPath:
             raise MiniVideoError("waves per picture must be 0 (auto), 4, 8 or 16")
 
     def set_layout(self, layout):
-        """0 auto, 1 one picture per workgroup (rows), 2 four pictures per workgroup (quad); speed only."""
-        code = {"auto": 0, "rows": 1, "quad": 2, "oct": 3}.get(layout, layout)
+        """0 auto, 1 one picture per workgroup (rows), 2 four pictures per workgroup (quad), 3 eight (oct), 4 one picture over
+        several workgroups (wide), 5 four pictures over several workgroups (quad_wide); speed only."""
+        code = LAYOUTS.index(layout) if layout in LAYOUTS else layout
         if self._L.mvhp_set_layout(self._h, int(code)) != SUCCESS:
-            raise ValueError("layout must be auto/rows/quad/oct")
+            raise ValueError("layout must be one of " + "/".join(LAYOUTS))
 
     def set_fused_color(self, on):
         self._L.mvhp_set_fused_color(self._h, 1 if on else 0)
@@ -186,7 +190,7 @@ class HotPath:
         """(layout name, waves per workgroup) of the last reconstruction launch -- speed-only choices of the launcher."""
         lay, nw = C.c_int(0), C.c_int(0)
         self._L.mvhp_last_launch_info(self._h, C.byref(lay), C.byref(nw))
-        return {0: "auto", 1: "rows", 2: "quad", 3: "oct"}.get(lay.value, "?"), nw.value
+        return (LAYOUTS[lay.value] if 0 <= lay.value < len(LAYOUTS) else "?"), nw.value
 
 
 # ---------------------------------------------------------------------------
