@@ -315,7 +315,7 @@ def end_to_end(args, params, stream, n_distinct, rec, want_rgb, total, rank, wor
         "h2d": {"busy_s": st["h2d_s"], "share_of_wall": st["h2d_s"] / w, "GB/s": st["h2d_bytes"] / max(st["h2d_s"], 1e-9) / 1e9},
         "kernels": {"busy_s": st["kernel_s"], "share_of_wall": st["kernel_s"] / w, "launches": st["batches"],
                     "largest_batch": st["max_batch_pictures"],
-                    "by_layout": dict(zip(["auto", "rows", "quad", "oct"], st["launches_by_layout"]))},
+                    "by_layout": dict(zip(["auto", "rows", "quad", "oct", "wide", "quad_wide"], list(st["launches_by_layout"]) + list(st["launches_wide"])))},
         "d2h": {"busy_s": st["d2h_s"], "share_of_wall": st["d2h_s"] / w, "GB/s": st["d2h_bytes"] / max(st["d2h_s"], 1e-9) / 1e9},
     }
     bound = max(stages, key=lambda k: stages[k]["share_of_wall"])
@@ -386,7 +386,7 @@ def engine_multi_context(args, params, stream, n_distinct, rec, want_rgb, n_ctx,
         "rehearsal_contexts_share_devices": n_ctx > n_devices,
         "value": pictures * params.mbs / wall, "unit": "macroblocks/s", "pictures": pictures, "wall_s": wall,
         "contexts": st["contexts"], "launches": st["batches"], "largest_batch": st["max_batch_pictures"],
-        "by_layout": dict(zip(["auto", "rows", "quad", "oct"], st["launches_by_layout"])),
+        "by_layout": dict(zip(["auto", "rows", "quad", "oct", "wide", "quad_wide"], list(st["launches_by_layout"]) + list(st["launches_wide"]))),
         "entropy_share_of_wall": st["entropy_busy_s"] / max(1, st["host_threads"]) / st["wall_s"],
         "bit_exact_vs_oracle": ok,
     }

@@ -293,7 +293,7 @@ typedef struct mvhp_decode_stats {
     uint32_t batches_requeued;     /* batches that failed on one context and were re-queued to another               */
     uint32_t contexts;
     uint32_t host_threads;
-    uint32_t launches_by_layout[4];/* indexed by MVHP_LAYOUT_*                                                       */
+    uint32_t launches_by_layout[4];/* indexed by MVHP_LAYOUT_AUTO .. MVHP_LAYOUT_OCT; the wide forms: launches_wide below   */
     uint32_t max_batch_pictures;
     double   wall_s;               /* whole call                                                                     */
     double   entropy_busy_s;       /* summed over host threads                                                       */
@@ -309,6 +309,7 @@ typedef struct mvhp_decode_stats {
     uint64_t host_alloc_bytes, dev_alloc_bytes;
     uint32_t placed_buffers;       /* 1: the device batch buffers come from mvhp_placed_alloc (MINIVIDEO_PLACED=1)   */
     uint32_t reserved;
+    uint32_t launches_wide[2];     /* launches on MVHP_LAYOUT_WIDE, MVHP_LAYOUT_QUAD_WIDE (launches_by_layout covers 0..3)  */
 } mvhp_decode_stats_t;
 
 /* Called on the calling thread, once per picture, in the order of `order`.  rc = MVHP_SUCCESS: yuv (and rgb when

@@ -193,41 +193,53 @@ MVHP_EXPORT int mvhp_set_fused_color(mvhp_ctx_t *c, int on)
     return MVHP_SUCCESS;
 }
 
-// largest batch the one-picture kernel reconstructs in bands (MVHP_LAYOUT_WIDE) rather than one workgroup per picture
-static int wide_rows_max(const mvhp_ctx *c) { return c->n_cus / 2; }
-
+// Which kernel form a batch runs on: speed only, results identical.
+//   Few pictures: ONE picture (one group of four) spread over several workgroups, bands of four macroblock rows each
+//   ("wide" forms: SURVEY 7 step 5's "grid = F x PicHeightInMbs wavefronts"); many pictures: one workgroup per group of
+//   four / eight.  Measured on 1080p Baseline (tools/layout_crossover.py, profiles/r04*_crossover_*.log; ms per launch):
+//     pictures        4     16     64    128    256    512    768   1024
+//     rows          2.47   2.49   2.53   2.55   2.58   5.00     -    8.86     one workgroup per picture (round 1-3)
+//     quad          3.99   4.00   4.00   4.02   4.05   4.16   4.32   4.48     ... per four pictures
+//     wide          1.01   1.02   1.28   1.61   2.44   4.40     -    8.51     one picture in 17 bands
+//     quad_wide       -    1.38   1.45   1.65   2.00   2.89   3.91   4.96     four pictures in 17 bands
+//   so: wide up to CUs / 2 pictures of 68 rows, quad_wide up to 3.5 x CUs, then the round model of rounds 2-3 between the
+//   four- and the eight-picture kernel.  The thresholds scale with the rows of a picture (what fills the chip is row-waves).
 static int pick_layout(const mvhp_ctx *c, const mvhp_stream_params_t *p, int n_frames)
 {
     int layout = c->layout;
     // pictures of several slices and scaling matrices (MVHP_STREAM_SPEC streams): the one-picture kernel,
-    // where a neighbour's availability is a per-wavefront scalar and LevelScale is a table in LDS -- whatever was asked for
-    if (p->flags & (MVHP_PARAM_SLICES | MVHP_PARAM_SCALING))
-        return (layout == MVHP_LAYOUT_ROWS || (layout != MVHP_LAYOUT_WIDE && n_frames > wide_rows_max(c))) ? MVHP_LAYOUT_ROWS : MVHP_LAYOUT_WIDE;
+    // where a neighbour's availability is a per-wavefront scalar and LevelScale is a table in LDS -- whatever was asked for;
+    // in bands at every batch size (2.44 against 2.58 ms at 256 pictures, 8.5 against 8.9 at 1024) unless "rows" is forced
+    if (p->flags & (MVHP_PARAM_SLICES | MVHP_PARAM_SCALING)) return (layout == MVHP_LAYOUT_ROWS) ? MVHP_LAYOUT_ROWS : MVHP_LAYOUT_WIDE;
     if (layout == MVHP_LAYOUT_AUTO) {
-        // speed only.  A launch is a number of "rounds" of one workgroup per CU (the batch kernels fill a CU with one
-        // workgroup); measured on 1080p, in units of one full round of the four-picture kernel (5.4 ms for 4 * CUs
-        // pictures): a round of the one-picture kernel (CUs pictures) 0.47; the four-picture kernel 0.77 with one
-        // workgroup on the device .. 1.0 with all CUs busy; the eight-picture kernel 1.48 .. 1.85 (8 * CUs pictures).
-        // (tools/layout_crossover.py: Baseline 256 pictures rows 2.6 / quad 4.2 / oct 8.0 ms, 1024: 8.7 / 5.4 / 8.3,
-        // 1536: 12.2 / 9.7 / 8.6, 2048: 15.8 / 10.6 / 10.0; High the same order.)
         const double cus = (double)c->n_cus;
-        auto rounds = [&](double per_round, double lo, double hi) {
-            const double full = floor(n_frames / per_round), rem = n_frames - full * per_round;
-            return full * hi + (rem > 0 ? lo + (hi - lo) * rem / per_round : 0.0);
-        };
-        const double t_rows = ceil(n_frames / cus) * 0.47;
-        const double t_quad = rounds(4 * cus, 0.77, 1.0);
-        const bool oct_fits = mvhp::recon_oct_lds_bytes((int)p->width_mbs, 8) <= c->max_lds;   // with six waves it loses to quad
-        const double t_oct = oct_fits ? rounds(8 * cus, 1.48, 1.85) : 1e30;
-        layout = (t_rows <= t_quad && t_rows <= t_oct) ? MVHP_LAYOUT_ROWS : (t_oct < t_quad ? MVHP_LAYOUT_OCT : MVHP_LAYOUT_QUAD);
-        // few pictures: spread each over several workgroups
-        if (layout == MVHP_LAYOUT_ROWS && n_frames <= wide_rows_max(c)) layout = MVHP_LAYOUT_WIDE;
+        const double row_waves = (double)n_frames * (double)p->height_mbs;
+        if (row_waves <= 34.0 * cus) {
+            layout = MVHP_LAYOUT_WIDE;
+        } else if (row_waves <= 238.0 * cus) {
+            layout = MVHP_LAYOUT_QUAD_WIDE;
+        } else {
+            // A launch is a number of "rounds" of one workgroup per CU (the batch kernels fill a CU with one workgroup), in
+            // units of one full round of the four-picture kernel (5.4 ms for 4 * CUs pictures of 1080p): the four-picture
+            // kernel 0.77 with one workgroup on the device .. 1.0 with all CUs busy; the eight-picture kernel 1.48 .. 1.85
+            // (8 * CUs pictures).  (1024 pictures: quad 5.4 / oct 8.3 ms, 1536: 9.7 / 8.6, 2048: 10.6 / 10.0.)
+            auto rounds = [&](double per_round, double lo, double hi) {
+                const double full = floor(n_frames / per_round), rem = n_frames - full * per_round;
+                return full * hi + (rem > 0 ? lo + (hi - lo) * rem / per_round : 0.0);
+            };
+            const double t_quad = rounds(4 * cus, 0.77, 1.0);
+            const bool oct_fits = mvhp::recon_oct_lds_bytes((int)p->width_mbs, 8) <= c->max_lds;   // with six waves it loses to quad
+            const double t_oct = oct_fits ? rounds(8 * cus, 1.48, 1.85) : 1e30;
+            layout = (t_oct < t_quad) ? MVHP_LAYOUT_OCT : MVHP_LAYOUT_QUAD;
+        }
     }
     // the batch kernels address a workgroup's pictures with 32-bit offsets and keep one line buffer per picture in LDS
     const size_t mbs = (size_t)p->width_mbs * p->height_mbs;
     if (layout == MVHP_LAYOUT_OCT && (mbs > ((size_t)1 << 19) || mvhp::recon_oct_lds_bytes((int)p->width_mbs, 4) > c->max_lds))
         layout = MVHP_LAYOUT_QUAD;
     if (layout == MVHP_LAYOUT_QUAD && mvhp::recon_quad_lds_bytes((int)p->width_mbs, 4) > c->max_lds) layout = MVHP_LAYOUT_ROWS;
+    if (layout == MVHP_LAYOUT_QUAD_WIDE && (mbs > ((size_t)1 << 20) || mvhp::recon_quad_lds_bytes((int)p->width_mbs, 4) > c->max_lds))
+        layout = MVHP_LAYOUT_WIDE;
     return layout;
 }
 
@@ -235,6 +247,14 @@ static int pick_waves(const mvhp_ctx *c, const mvhp_stream_params_t *p, int n_fr
 {
     int nw = c->waves;
     if (layout == MVHP_LAYOUT_WIDE) return 4;   // rows per band (built for 4: the finest grain, 17 bands per 1080p picture)
+    if (layout == MVHP_LAYOUT_QUAD_WIDE) {
+        // rows per band, built for 4 and 8: 8-wave workgroups fit two to a CU (LDS) = 16 waves, 4-wave ones three = 12;
+        // the finer grain is the faster one at every batch size measured (512 x 1080p: 2.89 against 2.99 ms)
+        if (nw == 0) nw = 4;
+        nw = (nw >= 8) ? 8 : 4;
+        if (nw == 8 && mvhp::recon_quad_lds_bytes((int)p->width_mbs, 8) > c->max_lds) nw = 4;
+        return nw;
+    }
     if (layout == MVHP_LAYOUT_OCT) {
         // speed only: built for 4, 6 and 8 waves; one workgroup per CU (LDS)
         static const int opts[3] = {8, 6, 4};
@@ -346,6 +366,12 @@ static int launch_all(mvhp_ctx *c, const mvhp_stream_params_t *p, const void *d_
             if (rc != MVHP_SUCCESS) return rc;
             HIP_TRY(mvhp::launch_recon_wide(a, n_frames, nw, st));
             c->ticket_base += (uint32_t)n_frames * (uint32_t)((a.height_mbs + nw - 1) / nw);   // every workgroup takes one ticket
+            HIP_TRY(hipEventRecord(c->wide_done, st));
+        } else if (layout == MVHP_LAYOUT_QUAD_WIDE) {
+            const int rc = wide_prepare(c, a, mvhp::recon_wide_seam_bytes(a.width_mbs, a.height_mbs, n_frames, nw), 0, st);
+            if (rc != MVHP_SUCCESS) return rc;
+            HIP_TRY(mvhp::launch_recon_quad_wide(a, nw, st));
+            c->ticket_base += (uint32_t)((n_frames + 3) / 4) * (uint32_t)((a.height_mbs + nw - 1) / nw);
             HIP_TRY(hipEventRecord(c->wide_done, st));
         } else if (layout == MVHP_LAYOUT_OCT) {
             HIP_TRY(mvhp::launch_recon_oct(a, nw, st));

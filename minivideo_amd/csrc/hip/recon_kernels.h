@@ -60,6 +60,8 @@ hipError_t launch_recon_wide(const ReconArgs &a, int n_frames, int nw, hipStream
 // four pictures per workgroup, 16 lanes per picture (recon_quad.hip)
 size_t     recon_quad_lds_bytes(int width_mbs, int nw);
 hipError_t launch_recon_quad(const ReconArgs &a, int nw, hipStream_t stream);
+// ... in bands of `nw` (4 or 8) rows over several workgroups (seams sized for 4 * ceil(n_frames / 4) pictures)
+hipError_t launch_recon_quad_wide(const ReconArgs &a, int nw, hipStream_t stream);
 // eight pictures per workgroup, 8 lanes per picture (recon_oct.hip)
 size_t     recon_oct_lds_bytes(int width_mbs, int nw);
 hipError_t launch_recon_oct(const ReconArgs &a, int nw, hipStream_t stream);

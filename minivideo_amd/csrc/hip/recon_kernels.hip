@@ -558,9 +558,11 @@ __global__ __launch_bounds__(NW * 64) void recon_rows_kernel(ReconArgs a)
 
     const int bands = (H + NW - 1) / NW;
     const int unit = WIDE ? __builtin_amdgcn_readfirstlane(B.unit) : 0;
-    const int frame = WIDE ? unit / bands : (int)blockIdx.x;
-    const int band = WIDE ? unit - frame * bands : 0;
-    if (WIDE && (unsigned)frame >= (unsigned)a.n_frames) return;   // (cannot happen: the grid has n_frames * bands workgroups)
+    // band-major: band b of every picture before band b + 1 of any -- when the batch outnumbers the resident workgroups, a
+    // band then starts about when the band above it has got ahead, instead of holding a slot idle from the launch on
+    const int band = WIDE ? unit / a.n_frames : 0;
+    const int frame = WIDE ? unit - band * a.n_frames : (int)blockIdx.x;
+    if (WIDE && (unsigned)band >= (unsigned)bands) return;   // (cannot happen: the grid has n_frames * bands workgroups)
     const int row_first = WIDE ? band * NW : 0;
     const int row_end = WIDE ? min(H, row_first + NW) : H;
     // seams: the first row of a band below the first takes its top neighbours from the seam above; the last row of a band

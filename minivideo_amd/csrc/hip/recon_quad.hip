@@ -45,7 +45,12 @@ namespace mvhp {
 // record prefetch registers, named only inside inline assembly, so
 // that nothing the compiler generates (copies, spills, reuse as temporaries) can touch a register a load is
 // still writing.
-template <int NW, bool RGB>
+// WIDE: as recon_rows_kernel<.., WIDE> (recon_kernels.hip): a workgroup reconstructs ONE BAND -- NW consecutive macroblock rows,
+// one per wavefront, a single pass -- of its four pictures, the bands of a group run on different CUs, units (band, group) come
+// from a ticket counter in band-major order, and across a band boundary the bottom samples travel as 8-byte tagged granules
+// (one agent-scope store each, polled with agent-scope loads; no flag, no fence).  512 pictures = 128 groups fill the chip
+// with 128 * bands workgroups where the one-workgroup-per-group form leaves half the CUs idle.
+template <int NW, bool RGB, bool WIDE>
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_num_vgpr(100))) void recon_quad_kernel(ReconArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -55,6 +60,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_num_vgpr(100))) void
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane_c = threadIdx.x & 63;
     uint8_t *wave_lds = lines + (size_t)4 * W * 32 + (size_t)wave * 4 * sizeof(QLds);
+    if (WIDE && threadIdx.x == 0) B.pad[0] = (int)(atomicAdd(a.wide_ticket, 1u) - a.wide_base);
 
     // ---- one-time table setup ----
     for (int i = threadIdx.x; i < 52; i += NW * 64) {
@@ -81,17 +87,35 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_num_vgpr(100))) void
     const uint32_t plane_y = (uint32_t)W * H * 256, plane_c = (uint32_t)W * H * 64;
     const int up_wave = (wave + NW - 1) % NW;
 
+    // this workgroup's pictures (and, WIDE, its band of rows)
+    const int groups = (a.n_frames + 3) / 4;
+    const int bands = (H + NW - 1) / NW;
+    const int unit = WIDE ? __builtin_amdgcn_readfirstlane(B.pad[0]) : 0;
+    const int band = WIDE ? unit / groups : 0;                       // band-major: see recon_rows_kernel
+    const int grp = WIDE ? unit - band * groups : (int)blockIdx.x;
+    if (WIDE && (unsigned)band >= (unsigned)bands) return;          // (cannot happen: the grid has groups * bands workgroups)
+    const int row_first = WIDE ? band * NW : 0;
+    const int row_end = WIDE ? min(H, row_first + NW) : H;
+    const bool seam_in = WIDE && wave == 0 && band > 0;             // top neighbours of this row come from the seam above
+    const bool seam_out = WIDE && wave == NW - 1 && row_first + NW < H;   // this row's bottom samples feed the seam below
+
     // this lane's picture
     const int q_c = lane_c >> 4;
-    const int frame_raw = (int)blockIdx.x * 4 + q_c;
+    const int frame_raw = grp * 4 + q_c;
     const bool valid = frame_raw < a.n_frames;            // a short last workgroup repeats the last picture, stores off
     const int frame = min(frame_raw, a.n_frames - 1);
     // Addresses: a scalar base per workgroup (its first picture) plus a 32-bit per-lane offset -- four pictures of
     // the largest supported size (1024 x 1024 macroblocks) span < 4 GiB in every buffer.
-    const uint32_t qf = (uint32_t)(frame - (int)blockIdx.x * 4);
-    const uint8_t *gpacked = a.packed + (size_t)blockIdx.x * 4 * W * H * MVHP_MB_BYTES;
-    uint8_t *gyuv = a.yuv + (size_t)blockIdx.x * 4 * W * H * 384;
-    uint8_t *grgb = a.rgb + (size_t)blockIdx.x * 4 * W * H * 768;
+    const uint32_t qf = (uint32_t)(frame - grp * 4);
+    const uint8_t *gpacked = a.packed + (size_t)grp * 4 * W * H * MVHP_MB_BYTES;
+    uint8_t *gyuv = a.yuv + (size_t)grp * 4 * W * H * 384;
+    uint8_t *grgb = a.rgb + (size_t)grp * 4 * W * H * 768;
+    // seams of the group's first picture (scalar) + a 32-bit offset per lane: picture qf, granule (j & 7) of column (j >> 3)
+    const unsigned long long *seam_rd = seam_in ? a.seam + ((size_t)grp * 4 * (bands - 1) + (band - 1)) * W * SEAM_GRANULES : nullptr;
+    unsigned long long *seam_wr = seam_out ? a.seam + ((size_t)grp * 4 * (bands - 1) + band) * W * SEAM_GRANULES : nullptr;
+    const uint32_t seam_pic = (uint32_t)((bands - 1) * W * SEAM_GRANULES);   // granules per picture
+    // seam_in: the granule a lane has asked for, for the macroblock pair after the current one, lands in v[124:125] -- like
+    // the record prefetch, registers that only inline assembly names (the compiler's own are full)
     const uint32_t qmb = qf * (uint32_t)(W * H);   // macroblocks in front of this lane's picture (< 2^22): one register;
                                                    // the three byte offsets are one 24-bit multiply away
 #define OPACKED (__umul24(qmb_v, MVHP_MB_BYTES))
@@ -127,7 +151,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_num_vgpr(100))) void
                      : "memory", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111",
                        "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123");
     };
-    if (wave < H) prefetch(wave, 0, lane_c);
+    if (row_first + wave < row_end) prefetch(row_first + wave, 0, lane_c);
     asm volatile("s_waitcnt vmcnt(0)" : : : "memory");   // (a wave without rows never reads the registers)
 
     const int up_adj = __builtin_amdgcn_readfirstlane((wave == 0) ? -1 : 0); // wave 0 follows the last wave's previous pass
@@ -140,8 +164,8 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_num_vgpr(100))) void
     // lines that are completed piecemeal leave early: with 16-byte runs the write traffic doubled.)  The chroma rows of the
     // three parked macroblocks wait in LDS (Q.SC).
     v4i L0 = {0, 0, 0, 0}, L1 = L0, L2 = L0, L3 = L0;
-    for (int row = wave; row < H; row += NW) {
-        const int pass = row / NW;
+    for (int row = row_first + wave; row < row_end; row += NW) {
+        const int pass = WIDE ? 0 : row / NW;
         // MBs the upper wave finished before its row (row-1); kept scalar explicitly
         const int up_base = (pass + up_adj) * W;
         const bool Bv = row > 0;
@@ -171,9 +195,70 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_num_vgpr(100))) void
                            "=&v"(w[6]), "=&v"(w[7]), "=&v"(w[8]), "=&v"(w[9]), "=&v"(w[10]), "=&v"(w[11])               \
                          : "n"(N)                                                                                      \
                          : "memory")
-            if (n_st) MVHP_WAIT_PREFETCH(VM_STRIP);
-            else MVHP_WAIT_PREFETCH(0);
+            if (WIDE && seam_out) {   // one more store behind the prefetch: the previous step's seam granules
+                if (n_st) MVHP_WAIT_PREFETCH(VM_STRIP + 1);
+                else MVHP_WAIT_PREFETCH(1);
+            } else {
+                if (n_st) MVHP_WAIT_PREFETCH(VM_STRIP);
+                else MVHP_WAIT_PREFETCH(0);
+            }
 #undef MVHP_WAIT_PREFETCH
+            if (WIDE && seam_in && (mbx & 1) == 0) {
+                // Macroblocks mbx and mbx + 1 read columns <= mbx + 2 of the row above.  The first step of a row fetches columns
+                // 0..3 now (two rounds); every later even step finds (mbx + 1, mbx + 2) asked for two steps ago, and asks for
+                // (mbx + 3, mbx + 4).  Lane j of a quarter: column c0 + (j >> 3), granule j & 7 (0-3 luma dwords, 4-5 Cb, 6-7 Cr).
+                // Every vector-memory instruction here is inline assembly: a load the compiler knows of would make it wait for
+                // vmcnt(0) all over the step (it cannot see that the asm stores of the strip are not what it waits for).
+                // (a lane id of its own: nothing computed here is shared with -- and kept alive for -- the rest of the step)
+                int lane_s = lane_c;
+                asm volatile("" : "+v"(lane_s));
+                const int js = lane_s & 15, g = js & 7;
+                uint8_t *sline_y = lines + (size_t)(lane_s >> 4) * W * 32;
+                uint8_t *sline_cb = sline_y + W * 16, *sline_cr = sline_cb + W * 8;
+                const uint32_t lo = (uint32_t)(min(grp * 4 + (lane_s >> 4), a.n_frames - 1) - grp * 4) * seam_pic + (uint32_t)g;
+                auto seam_now = [&](uint32_t off) {   // blocking (first step of a row, and while a granule is not there yet)
+                    v2i pv;
+                    asm volatile("s_nop 4\n\tglobal_load_dwordx2 v[124:125], %1, %2 sc1\n\ts_waitcnt vmcnt(0)\n\tv_mov_b64 %0, v[124:125]"
+                                 : "=v"(pv) : "v"(off), "s"(seam_rd) : "memory", "v124", "v125");
+                    return pv;
+                };
+                int c0 = mbx ? mbx + 1 : 0;
+                for (int round = mbx ? 1 : 0; round < 2; round++, c0 += 2) {
+                    const int col = c0 + (js >> 3);
+                    const bool act = col < W;
+                    const uint32_t off = (lo + (uint32_t)((act ? col : 0) * SEAM_GRANULES)) * 8u;
+                    v2i pv;
+                    if (mbx == 0) pv = seam_now(off);
+                    else asm volatile("v_mov_b64 %0, v[124:125]" : "=v"(pv) : : "memory");   // asked for two steps ago, in front of two
+                                                                                           // record prefetches: the wait above saw it land
+                    int spins = 0;
+                    while (__builtin_amdgcn_ballot_w64(act && (uint32_t)pv.y != a.wide_epoch) != 0) {
+                        __builtin_amdgcn_s_sleep(2);
+                        // bounded; a failure anywhere in the launch (error word) ends every wait
+                        bool stop = ++spins > (1 << 20) || __hip_atomic_load(&B.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        if (!stop && (spins & 255) == 0) {
+                            uint32_t ew;
+                            asm volatile("s_nop 4\n\tglobal_load_dword v124, %1, %2 sc1\n\ts_waitcnt vmcnt(0)\n\tv_mov_b32 %0, v124"
+                                         : "=v"(ew) : "v"(0u), "s"(a.err) : "memory", "v124");
+                            stop = __builtin_amdgcn_ballot_w64(ew != 0) != 0;
+                        }
+                        if (stop) {
+                            if (lane_s == 0) { __hip_atomic_store(&B.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); atomicOr(a.err, 1u); }
+                            return;
+                        }
+                        pv = seam_now(off);
+                    }
+                    if (act) {
+                        uint8_t *dst = (g < 4) ? &sline_y[col * 16 + g * 4] : (g < 6) ? &sline_cb[col * 8 + (g - 4) * 4] : &sline_cr[col * 8 + (g - 6) * 4];
+                        *reinterpret_cast<uint32_t *>(dst) = (uint32_t)pv.x;
+                    }
+                }
+                {   // the request for the next pair (columns beyond the picture: the last column again, ignored later)
+                    const uint32_t off = (lo + (uint32_t)(min(mbx + 3 + (js >> 3), W - 1) * SEAM_GRANULES)) * 8u;
+                    asm volatile("s_nop 4\n\tglobal_load_dwordx2 v[124:125], %0, %1 sc1" : : "v"(off), "s"(seam_rd) : "memory", "v124", "v125");
+                }
+                WAVE_SYNC();
+            }
             const int4 cH0 = make_int4(w[0].x, w[0].y, w[1].x, w[1].y), cH1 = make_int4(w[2].x, w[2].y, w[3].x, w[3].y);
             const int4 cLA = make_int4(w[4].x, w[4].y, w[5].x, w[5].y), cLB = make_int4(w[6].x, w[6].y, w[7].x, w[7].y);
             const int4 cCA = make_int4(w[8].x, w[8].y, w[9].x, w[9].y), cCB = make_int4(w[10].x, w[10].y, w[11].x, w[11].y);
@@ -354,7 +439,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_num_vgpr(100))) void
                 // next row (none left: this one again)
                 int nrow = row, nx = mbx + 1;
                 if (nx >= W) { nrow = row + NW; nx = 0; }
-                if (nrow >= H) { nrow = row; nx = mbx; }
+                if (nrow >= row_end) { nrow = row; nx = mbx; }
                 prefetch(nrow, nx, lane);
             }
 
@@ -366,7 +451,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_num_vgpr(100))) void
 #else
             if (Bv) {
 #endif
-                const int need = up_base + min(mbx + 2, W);
+                const int need = (WIDE && seam_in) ? 0 : up_base + min(mbx + 2, W);   // (seam_in: the columns are in the line buffer)
                 int spins = 0;
                 while (__hip_atomic_load(&B.progress[up_wave], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < need) {
                     __builtin_amdgcn_s_sleep(1);
@@ -716,24 +801,27 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_num_vgpr(100))) void
                         n_st = VM_STRIP;
                     } else if (m_own <= mbi && valid) {
                         // ---- short strip at the right picture edge (W % 4 != 0): compiler-counted stores ----
-                        const v4i Lr[4] = {L0, L1, L2, L3};
-                        const uint2 cbr[2] = {cb0, cb1}, crr[2] = {cr0, cr1};
-#pragma unroll
-                        for (int i = 0; i < 2; i++) {
-                            *reinterpret_cast<v4i *>(gyuv + pl + 2 * i * pitch) = Lr[2 * i];
-                            *reinterpret_cast<v4i *>(gyuv + pl + (2 * i + 1) * pitch) = Lr[2 * i + 1];
-                            *reinterpret_cast<uint2 *>(gyuv + pcb + i * cpitch) = cbr[i];
-                            *reinterpret_cast<uint2 *>(gyuv + pcr + i * cpitch) = crr[i];
-                            if (RGB) {
-                                const uint32_t prgb = ORGB + lrow * 3u;
-#pragma unroll
-                                for (int r = 0; r < 2; r++) {
-                                    v4i a0, a1, a2;
-                                    const v4i yk = Lr[2 * i + r];
-                                    rgb16(make_uint4((uint32_t)yk.x, (uint32_t)yk.y, (uint32_t)yk.z, (uint32_t)yk.w), cbr[i], crr[i], a0, a1, a2);
-                                    v4i *dst = reinterpret_cast<v4i *>(grgb + prgb + (2 * i + r) * 3u * (uint32_t)pitch);
-                                    dst[0] = a0; dst[1] = a1; dst[2] = a2;
-                                }
+                        *reinterpret_cast<v4i *>(gyuv + pl) = L0;
+                        *reinterpret_cast<v4i *>(gyuv + pl + pitch) = L1;
+                        *reinterpret_cast<v4i *>(gyuv + pl + 2 * pitch) = L2;
+                        *reinterpret_cast<v4i *>(gyuv + pl + 3 * pitch) = L3;
+                        *reinterpret_cast<uint2 *>(gyuv + pcb) = cb0;
+                        *reinterpret_cast<uint2 *>(gyuv + pcr) = cr0;
+                        *reinterpret_cast<uint2 *>(gyuv + pcb + cpitch) = cb1;
+                        *reinterpret_cast<uint2 *>(gyuv + pcr + cpitch) = cr1;
+                        if (RGB) {
+                            // one row per trip of a loop that is NOT unrolled: with the four rows' colour arithmetic scheduled together
+                            // the compiler needs more registers than v0-v99 and reaches into the prefetch registers
+                            // (check_prefetch_hazard.py); the row is chosen by scalar selects
+                            const uint32_t prgb = ORGB + lrow * 3u;
+#pragma unroll 1
+                            for (int rr = 0; rr < 4; rr++) {
+                                const v4i yk = (rr == 0) ? L0 : (rr == 1) ? L1 : (rr == 2) ? L2 : L3;
+                                const uint2 cbq = (rr < 2) ? cb0 : cb1, crq = (rr < 2) ? cr0 : cr1;
+                                v4i a0, a1, a2;
+                                rgb16(make_uint4((uint32_t)yk.x, (uint32_t)yk.y, (uint32_t)yk.z, (uint32_t)yk.w), cbq, crq, a0, a1, a2);
+                                v4i *dst = reinterpret_cast<v4i *>(grgb + prgb + (uint32_t)rr * 3u * (uint32_t)pitch);
+                                dst[0] = a0; dst[1] = a1; dst[2] = a2;
                             }
                         }
                     }
@@ -769,6 +857,18 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_num_vgpr(100))) void
                 Q.LcolC[j >> 3][j & 7] = kc;
                 if (j < 3) *kdst = kk;
                 if (j < 8) *reinterpret_cast<uint32_t *>(bdst) = bot;
+                if (WIDE && seam_out) {
+                    // the same eight dwords, tagged, to the band below: one write-through store per granule -- inline assembly, see
+                    // the seam_in block; the address from a lane id made here (computed ahead, it would sit in registers through
+                    // the write-out)
+                    int lane_w = lane_c;
+                    asm volatile("" : "+v"(lane_w));
+                    const uint32_t pic = (uint32_t)(min(grp * 4 + (lane_w >> 4), a.n_frames - 1) - grp * 4);
+                    const uint32_t off = (pic * seam_pic + (uint32_t)(mbx * SEAM_GRANULES + (lane_w & 7))) * 8u;
+                    const v2i gv = {(int)bot, (int)a.wide_epoch};
+                    if ((lane_w & 15) < 8)
+                        asm volatile("s_nop 4\n\tglobal_store_dwordx2 %0, %1, %2 sc1" : : "v"(off), "v"(gv), "s"(seam_wr) : "memory");
+                }
             }
             done++;
             // LDS operations of one wave complete in order; the explicit wait makes the line-buffer
@@ -789,15 +889,29 @@ size_t recon_quad_lds_bytes(int width_mbs, int nw)
     return sizeof(QTables) + (size_t)4 * width_mbs * 32 + (size_t)nw * 4 * sizeof(QLds);
 }
 
-template <int NW, bool RGB>
+template <int NW, bool RGB, bool WIDE = false>
 static hipError_t launch_quad_one(const ReconArgs &a, hipStream_t stream)
 {
     const size_t lds = recon_quad_lds_bytes(a.width_mbs, NW);
     const int groups = (a.n_frames + 3) / 4;
-    hipError_t e = hipFuncSetAttribute((const void *)recon_quad_kernel<NW, RGB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const int bands = WIDE ? (a.height_mbs + NW - 1) / NW : 1;
+    hipError_t e = hipFuncSetAttribute((const void *)recon_quad_kernel<NW, RGB, WIDE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((recon_quad_kernel<NW, RGB>), dim3(groups), dim3(NW * 64), lds, stream, a);
+    hipLaunchKernelGGL((recon_quad_kernel<NW, RGB, WIDE>), dim3(groups * bands), dim3(NW * 64), lds, stream, a);
     return hipGetLastError();
+}
+
+// one workgroup per (band of nw rows, group of four pictures); a.wide_ticket / wide_base / wide_epoch / seam set by the caller
+hipError_t launch_recon_quad_wide(const ReconArgs &a, int nw, hipStream_t stream)
+{
+    if (!a.wide_ticket || !a.wide_epoch) return hipErrorInvalidValue;
+    if ((a.height_mbs + nw - 1) / nw > 1 && !a.seam) return hipErrorInvalidValue;
+    const bool rgb = a.rgb != nullptr;
+    switch (nw) {
+    case 4: return rgb ? launch_quad_one<4, true, true>(a, stream) : launch_quad_one<4, false, true>(a, stream);
+    case 8: return rgb ? launch_quad_one<8, true, true>(a, stream) : launch_quad_one<8, false, true>(a, stream);
+    default: return hipErrorInvalidValue;
+    }
 }
 
 hipError_t launch_recon_quad(const ReconArgs &a, int nw, hipStream_t stream)

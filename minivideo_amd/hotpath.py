@@ -252,7 +252,8 @@ class DecodeStats(C.Structure):
                 ("d2h_s", C.c_double), ("sink_s", C.c_double), ("stream_bytes", C.c_uint64), ("h2d_bytes", C.c_uint64),
                 ("d2h_bytes", C.c_uint64), ("host_alloc_s", C.c_double), ("dev_alloc_s", C.c_double),
                 ("first_launch_s", C.c_double), ("first_picture_s", C.c_double), ("host_alloc_bytes", C.c_uint64),
-                ("dev_alloc_bytes", C.c_uint64), ("placed_buffers", C.c_uint32), ("reserved", C.c_uint32)]
+                ("dev_alloc_bytes", C.c_uint64), ("placed_buffers", C.c_uint32), ("reserved", C.c_uint32),
+                ("launches_wide", C.c_uint32 * 2)]
 
     def as_dict(self):
         d = {}

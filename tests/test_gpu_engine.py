@@ -16,6 +16,11 @@ from tests.util import Stream
 
 pytestmark = pytest.mark.gpu
 
+
+def _cus():
+    import torch
+    return torch.cuda.get_device_properties(0).multi_processor_count
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CLI = os.path.join(ROOT, "minivideo_amd", "mini_thumbnailer")
 
@@ -97,11 +102,15 @@ def test_engine_wanted_caps_entropy_work():
         assert got[i][0] == k and np.array_equal(got[i][3], loader.recon(p, packed[k], 1)[0])
 
 
-@pytest.mark.parametrize("batch,layout", [(1024, 2), (2048, 3)])
-def test_engine_reaches_the_batch_kernels(batch, layout):
-    """4 x CUs pictures in one launch -> four pictures per workgroup; 8 x CUs -> eight (pick_layout, hotpath_abi.hip)."""
+@pytest.mark.parametrize("batch,forced,layout", [(1024, None, "wide"), (2048, None, "quad_wide"), (1024, "quad", "quad"), (2048, "oct", "oct")])
+def test_engine_reaches_the_batch_kernels(batch, forced, layout, monkeypatch):
+    """what pick_layout (hotpath_abi.hip) makes of the engine's large batches of SMALL pictures (6 rows: 1024 of them are 6144
+    row-waves -> the one-picture kernel in bands, 2048 -> the four-picture kernel in bands), and the one-workgroup-per-group
+    kernels forced through the environment (they are the automatic choice from ~900 full-HD pictures per launch on)"""
     W, H, D = 12, 6, 32
     F = 2080
+    if forced:
+        monkeypatch.setenv("MINIVIDEO_LAYOUT", forced)
     stream, packed = gen.make_stream(W, H, D, seed=80, profile="baseline")
     # the same D pictures over and over: SPS/PPS once, then the IDR NAL units repeated
     starts = [i for i in range(len(stream) - 4) if stream[i] == 0 and stream[i + 1] == 0 and stream[i + 2] == 0 and stream[i + 3] == 1]
@@ -122,7 +131,9 @@ def test_engine_reaches_the_batch_kernels(batch, layout):
         rc, st = eng.decode(s.h, list(range(F)), want_rgb=True, sink=sink)
     eng.close()
     assert rc == 1 and st["pictures_ok"] == F
-    assert st["launches_by_layout"][layout] >= 1, st
+    by_layout = dict(zip(["auto", "rows", "quad", "oct", "wide", "quad_wide"], list(st["launches_by_layout"]) + list(st["launches_wide"])))
+    if forced or _cus() == 256:
+        assert by_layout[layout] >= 1, by_layout
     for seq, (yuv, rgb) in hashes.items():
         ref_yuv, ref_rgb = loader.recon(p, packed[seq % D], 1, want_rgb=True)
         assert np.array_equal(yuv, ref_yuv) and np.array_equal(rgb, ref_rgb), seq

@@ -41,6 +41,15 @@ FAMILIES = {
 }
 
 
+def _in_asm(L, i):
+    for k in range(i, -1, -1):
+        if '#ASMEND' in L[k]:
+            return False
+        if '#ASMSTART' in L[k]:
+            return True
+    return False
+
+
 def check(L, name):
     """L = the lines of one kernel."""
     fam = next(v for k, v in FAMILIES.items() if k in name)
@@ -49,7 +58,8 @@ def check(L, name):
     if os.environ.get("MVHP_CHECK_STRIP_COUNTS"):
         strip_counts = tuple(int(v) for v in os.environ["MVHP_CHECK_STRIP_COUNTS"].split(","))
     first = "v[%d:%d]" % (min(PREFETCH), min(PREFETCH) + 1)
-    in_asm, touched, asm_loads, asm_stores_at = False, [], [], []
+    in_asm, touched, asm_loads, asm_stores_at, seam_stores = False, [], [], [], []
+    wide = "recon_quad_kernel" in name and name.endswith("Lb1EEEvNS_9ReconArgsE")   # recon_quad_kernel<NW, RGB, true>
     for i, raw in enumerate(L):
         if '#ASMSTART' in raw:
             in_asm = True
@@ -65,11 +75,29 @@ def check(L, name):
                 asm_loads.append(i)
                 require(regs(l.split(',')[0]) <= PREFETCH, name, l)
             elif re.match(r'\s+global_store', l):
-                asm_stores_at.append(i)
                 require(not (regs(l) & PREFETCH), name, l)
+                if re.search(r'\bsc1\b', l):
+                    seam_stores.append(i)    # wide instantiations: the granules for the band below (counted by the waits, below)
+                else:
+                    asm_stores_at.append(i)
         elif regs(l) & PREFETCH:
             touched.append((i, l))
     require(len(asm_loads) == 2 * n_block, name, len(asm_loads))      # one block in the prologue, one in the loop
+    # wide instantiations of the quad kernel (recon_quad_kernel<NW, RGB, true>): the seam granule a lane has asked for lands in
+    # v[124:125], requested two steps before its use -- registers the compiler must never name at all
+    require(len(seam_stores) == (1 if wide else 0), name, 'asm seam stores', seam_stores)
+    if wide:
+        seam = [(i, l) for i, l in enumerate(L) if re.match(r'\s+global_load_dwordx2 v\[124:125\].* sc1', l.split(';')[0])]
+        require(len(seam) >= 2, name, 'asm seam loads expected (blocking form and request)', seam)
+        in_a, bad = False, []
+        for i, raw in enumerate(L):
+            if '#ASMSTART' in raw:
+                in_a = True
+            elif '#ASMEND' in raw:
+                in_a = False
+            elif not in_a and regs(raw.split(';')[0]) & {124, 125}:
+                bad.append((i, raw))
+        require(not bad, name, 'compiler code names the seam registers v124 / v125', bad[:5])
     # (d) hazard padding inside every asm block that touches vector memory
     blk = None
     for i, raw in enumerate(L):
@@ -91,10 +119,15 @@ def check(L, name):
                 blk.append(t)
     # the guarded waits: asm blocks that start with s_waitcnt vmcnt(N) and then move the prefetch registers out
     waits = [i for i, l in enumerate(L) if re.search(r's_waitcnt vmcnt\(\d+\)', l) and first in L[i + 1]]
-    require(len(waits) == 2, name, waits)
     counts = sorted(int(re.search(r'vmcnt\((\d+)\)', L[w]).group(1)) for w in waits)
-    require(counts[0] == 0 and counts[1] in strip_counts, name, counts)
-    n_expect = counts[1]
+    if wide:   # a wave that feeds a seam has one more store behind its prefetch: waits for N + 1
+        require(len(waits) == 4, name, waits)
+        require(counts[0] == 0 and counts[1] == 1 and counts[2] in strip_counts and counts[3] == counts[2] + 1, name, counts)
+        n_expect = counts[2]
+    else:
+        require(len(waits) == 2, name, waits)
+        require(counts[0] == 0 and counts[1] in strip_counts, name, counts)
+        n_expect = counts[1]
     w0 = min(waits)
     # the macroblock loop: the nearest label above the waits that a later instruction branches back to
     labi, back = None, []
@@ -117,6 +150,10 @@ def check(L, name):
     pro = [i for i in asm_loads if i < labi]
     bad = [(i, l) for i, l in touched if pro and pro[0] <= i < labi]
     require(not bad, name, 'compiler code touches the prefetch registers behind the prologue loads', bad[:5])
+    if wide:   # no vector load the compiler knows of inside the macroblock loop: it would wait for vmcnt(0) all over the step
+        vis = [(i, L[i]) for i in range(labi, max(back) + 1)
+               if re.match(r'\s+(global|flat|buffer)_load', L[i].split(';')[0]) and not _in_asm(L, i)]
+        require(not vis, name, 'compiler-visible vector loads in the loop of a wide kernel', vis[:5])
     spills = [i for i in range(labi, max(back) + 1) if re.match(r'\s+scratch_', L[i])]
     require(not spills, name, 'scratch access inside the macroblock loop', spills[:3])
     in_loop = [i for i in asm_stores_at if labi <= i <= max(back)]
