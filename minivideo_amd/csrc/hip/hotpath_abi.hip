@@ -126,6 +126,7 @@ MVHP_EXPORT int mvhp_create(int device, mvhp_ctx_t **out)
         else if (!strcmp(e, "oct")) c->layout = MVHP_LAYOUT_OCT;
         else if (!strcmp(e, "wide")) c->layout = MVHP_LAYOUT_WIDE;
         else if (!strcmp(e, "quad_wide")) c->layout = MVHP_LAYOUT_QUAD_WIDE;
+        else if (!strcmp(e, "pipe")) c->layout = MVHP_LAYOUT_PIPE;
     }
     c->n_cus = prop.multiProcessorCount;
     c->max_lds = prop.maxSharedMemoryPerMultiProcessor ? prop.maxSharedMemoryPerMultiProcessor : 65536;
@@ -159,7 +160,7 @@ MVHP_EXPORT void mvhp_destroy(mvhp_ctx_t *c)
 
 MVHP_EXPORT int mvhp_set_waves_per_picture(mvhp_ctx_t *c, int waves)
 {
-    if (!c || !(waves == 0 || waves == 4 || waves == 6 || waves == 8 || waves == 12 || waves == 16)) return MVHP_FAILURE;
+    if (!c || !(waves == 0 || waves == 1 || waves == 2 || waves == 4 || waves == 6 || waves == 8 || waves == 12 || waves == 16)) return MVHP_FAILURE;
     c->waves = waves;
     return MVHP_SUCCESS;
 }
@@ -202,8 +203,16 @@ MVHP_EXPORT int mvhp_set_fused_color(mvhp_ctx_t *c, int on)
 //     quad          3.99   4.00   4.00   4.02   4.05   4.16   4.32   4.48     ... per four pictures
 //     wide          1.01   1.02   1.28   1.61   2.44   4.40     -    8.51     one picture in 17 bands
 //     quad_wide       -    1.38   1.45   1.65   2.00   2.89   3.91   4.96     four pictures in 17 bands
+//     pipe (4 rows)  0.73 (one picture)  0.98   1.20   1.51   2.29   3.97     four pictures in 17 bands, three waves per row
 //   so: wide up to CUs / 2 pictures of 68 rows, quad_wide up to 3.5 x CUs, then the round model of rounds 2-3 between the
 //   four- and the eight-picture kernel.  The thresholds scale with the rows of a picture (what fills the chip is row-waves).
+//   High profile (Intra8x8 in the mix; the same table in profiles/r04d_crossover_high*.log): wide 1.07 / 1.37 / 1.69 / 2.58 /
+//   4.61 ms at 16 / 64 / 128 / 256 / 512 pictures against quad_wide 1.91 / 2.05 / 2.39 / 2.84 / 3.95 -- the four pictures of a
+//   wavefront run their three luma paths one after the other -- so wide up to 1.3 x CUs pictures there.
+//   The three-waves-per-row form (pipe) is within 8 % of wide on Baseline and 20-30 % behind it on High: the step is the
+//   prediction chain, LDS round trip by LDS round trip, and taking residuals and write-out off it shortens it less than four
+//   pictures in lock step lengthen it.  It wins where the four quarters of a wavefront hold the SAME picture (a short group of
+//   up to three pictures: no divergence), 0.73 against 1.00 ms -- the single-thumbnail case.
 static int pick_layout(const mvhp_ctx *c, const mvhp_stream_params_t *p, int n_frames)
 {
     int layout = c->layout;
@@ -214,7 +223,10 @@ static int pick_layout(const mvhp_ctx *c, const mvhp_stream_params_t *p, int n_f
     if (layout == MVHP_LAYOUT_AUTO) {
         const double cus = (double)c->n_cus;
         const double row_waves = (double)n_frames * (double)p->height_mbs;
-        if (row_waves <= 34.0 * cus) {
+        const bool may8 = (p->flags & MVHP_PARAM_MAY_HAVE_8X8) != 0;
+        if (n_frames <= 3 && mvhp::recon_pipe_lds_bytes((int)p->width_mbs, 4) <= c->max_lds) {
+            layout = MVHP_LAYOUT_PIPE;
+        } else if (row_waves <= (may8 ? 90.0 : 34.0) * cus) {
             layout = MVHP_LAYOUT_WIDE;
         } else if (row_waves <= 238.0 * cus) {
             layout = MVHP_LAYOUT_QUAD_WIDE;
@@ -238,6 +250,8 @@ static int pick_layout(const mvhp_ctx *c, const mvhp_stream_params_t *p, int n_f
     if (layout == MVHP_LAYOUT_OCT && (mbs > ((size_t)1 << 19) || mvhp::recon_oct_lds_bytes((int)p->width_mbs, 4) > c->max_lds))
         layout = MVHP_LAYOUT_QUAD;
     if (layout == MVHP_LAYOUT_QUAD && mvhp::recon_quad_lds_bytes((int)p->width_mbs, 4) > c->max_lds) layout = MVHP_LAYOUT_ROWS;
+    if (layout == MVHP_LAYOUT_PIPE && (mbs > ((size_t)1 << 20) || mvhp::recon_pipe_lds_bytes((int)p->width_mbs, 1) > c->max_lds))
+        layout = MVHP_LAYOUT_QUAD_WIDE;
     if (layout == MVHP_LAYOUT_QUAD_WIDE && (mbs > ((size_t)1 << 20) || mvhp::recon_quad_lds_bytes((int)p->width_mbs, 4) > c->max_lds))
         layout = MVHP_LAYOUT_WIDE;
     return layout;
@@ -246,6 +260,13 @@ static int pick_layout(const mvhp_ctx *c, const mvhp_stream_params_t *p, int n_f
 static int pick_waves(const mvhp_ctx *c, const mvhp_stream_params_t *p, int n_frames, int layout)
 {
     int nw = c->waves;
+    if (layout == MVHP_LAYOUT_PIPE) {
+        // rows per band (three wavefronts each), built for 1, 2 and 4
+        if (nw == 0) nw = 4;
+        nw = (nw >= 4) ? 4 : (nw >= 2 ? 2 : 1);
+        while (nw > 1 && mvhp::recon_pipe_lds_bytes((int)p->width_mbs, nw) > c->max_lds) nw /= 2;
+        return nw;
+    }
     if (layout == MVHP_LAYOUT_WIDE) return 4;   // rows per band (built for 4: the finest grain, 17 bands per 1080p picture)
     if (layout == MVHP_LAYOUT_QUAD_WIDE) {
         // rows per band, built for 4 and 8: 8-wave workgroups fit two to a CU (LDS) = 16 waves, 4-wave ones three = 12;
@@ -366,6 +387,12 @@ static int launch_all(mvhp_ctx *c, const mvhp_stream_params_t *p, const void *d_
             if (rc != MVHP_SUCCESS) return rc;
             HIP_TRY(mvhp::launch_recon_wide(a, n_frames, nw, st));
             c->ticket_base += (uint32_t)n_frames * (uint32_t)((a.height_mbs + nw - 1) / nw);   // every workgroup takes one ticket
+            HIP_TRY(hipEventRecord(c->wide_done, st));
+        } else if (layout == MVHP_LAYOUT_PIPE) {
+            const int rc = wide_prepare(c, a, mvhp::recon_wide_seam_bytes(a.width_mbs, a.height_mbs, n_frames, nw), 0, st);
+            if (rc != MVHP_SUCCESS) return rc;
+            HIP_TRY(mvhp::launch_recon_pipe(a, nw, st));
+            c->ticket_base += (uint32_t)((n_frames + 3) / 4) * (uint32_t)((a.height_mbs + nw - 1) / nw);
             HIP_TRY(hipEventRecord(c->wide_done, st));
         } else if (layout == MVHP_LAYOUT_QUAD_WIDE) {
             const int rc = wide_prepare(c, a, mvhp::recon_wide_seam_bytes(a.width_mbs, a.height_mbs, n_frames, nw), 0, st);

@@ -62,6 +62,9 @@ size_t     recon_quad_lds_bytes(int width_mbs, int nw);
 hipError_t launch_recon_quad(const ReconArgs &a, int nw, hipStream_t stream);
 // ... in bands of `nw` (4 or 8) rows over several workgroups (seams sized for 4 * ceil(n_frames / 4) pictures)
 hipError_t launch_recon_quad_wide(const ReconArgs &a, int nw, hipStream_t stream);
+// four pictures per wavefront in bands of four rows, three wavefronts per row (recon_pipe.hip); seams as the wide form with nw = 4
+size_t     recon_pipe_lds_bytes(int width_mbs, int rows);
+hipError_t launch_recon_pipe(const ReconArgs &a, int rows, hipStream_t stream);   // rows per band: 1, 2 or 4
 // eight pictures per workgroup, 8 lanes per picture (recon_oct.hip)
 size_t     recon_oct_lds_bytes(int width_mbs, int nw);
 hipError_t launch_recon_oct(const ReconArgs &a, int nw, hipStream_t stream);

@@ -102,7 +102,7 @@ def _tile_on_device(torch, packed, n):
 # pictures per launch -> the kernel pick_layout takes on a 256-CU MI355X (hotpath_abi.hip: one picture over 17 workgroups up to
 # CUs / 2 pictures, four pictures over 17 workgroups up to 3.5 x CUs, then one workgroup per four pictures, and per eight for
 # whole rounds of eight per CU)
-@pytest.mark.parametrize("n,layout", [(64, "wide"), (512, "quad_wide"), (1024, "quad"), (2048, "oct"), (2080, "quad")])
+@pytest.mark.parametrize("n,layout", [(2, "pipe"), (64, "wide"), (512, "quad_wide"), (1024, "quad"), (2048, "oct"), (2080, "quad")])
 def test_full_hd_batches_on_the_automatic_layout(torch_cuda, base1080, n, layout):
     torch = torch_cuda
     _, packed, p, ref = base1080
@@ -125,7 +125,7 @@ def test_full_hd_batches_on_the_automatic_layout(torch_cuda, base1080, n, layout
     rgb = d_rgb.view(n, -1)
     # every distinct picture once at the front, once at the back, and a sample in between
     sample = sorted(set(range(min(16, n))) | set(range(max(0, n - 16), n)) | set(range(0, n, 131)))
-    assert len(sample) >= 8
+    assert len(sample) >= min(8, n)
     for f in sample:
         yuv_o, rgb_o = ref[f % 16]
         assert np.array_equal(yuv[f].cpu().numpy(), yuv_o), f

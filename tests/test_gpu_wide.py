@@ -21,7 +21,7 @@ from oracle import loader
 
 pytestmark = pytest.mark.gpu
 
-WIDE = ("wide", "quad_wide")
+WIDE = ("wide", "quad_wide", "pipe")
 
 
 @pytest.fixture(scope="module")
@@ -115,16 +115,16 @@ def test_band_boundaries(layout, W, H):
 
 
 def test_automatic_choice_by_batch_size(torch_cuda):
-    """pick_layout on a 256-CU device: row-waves (pictures x rows) <= 34 x CUs -> one picture in bands, <= 238 x CUs -> four
-    pictures in bands; slices / scaling batches: the one-picture kernel in bands at every size"""
+    """pick_layout on a 256-CU device: up to three pictures -> three waves per row (the quarters of a wavefront hold the same
+    picture); row-waves (pictures x rows) <= 34 x CUs -> one picture in bands, <= 238 x CUs -> four pictures in bands"""
     torch = torch_cuda
     if torch.cuda.get_device_properties(0).multi_processor_count != 256:
         pytest.skip("thresholds are stated for 256 CUs")
     hot = HotPath(0)
     try:
         hot.set_layout("auto")
-        for (W, H, n, want) in [(20, 17, 1, "wide"), (20, 17, 512, "wide"), (20, 17, 513, "quad_wide"), (20, 68, 128, "wide"),
-                                (20, 68, 129, "quad_wide"), (6, 68, 896, "quad_wide"), (6, 68, 897, "quad")]:
+        for (W, H, n, want) in [(20, 17, 1, "pipe"), (20, 17, 3, "pipe"), (20, 17, 4, "wide"), (20, 17, 512, "wide"), (20, 17, 513, "quad_wide"),
+                                (20, 68, 128, "wide"), (20, 68, 129, "quad_wide"), (6, 68, 896, "quad_wide"), (6, 68, 897, "quad")]:
             params, rec = synth_packed(W, H, 4, seed=7, profile="baseline", density="light")
             d_packed = _tile(torch, rec, n)
             d_yuv = torch.empty(n * params.yuv_bytes, dtype=torch.uint8, device="cuda")
@@ -158,7 +158,7 @@ def test_bookkeeping_across_launches(torch_cuda):
             W, H = list(shapes)[int(rng.integers(0, 3))]
             params, rec, ref = shapes[(W, H)]
             n = int(rng.choice([1, 3, 4, 9, 30, 70]))
-            layout = WIDE[it & 1]
+            layout = WIDE[it % 3]
             hot.set_layout(layout)
             st = streams[int(rng.integers(0, 2))]
             d_packed = _tile(torch, rec, n)
