@@ -44,15 +44,15 @@ extern "C" {
 #define FAILURE       0
 #define SUCCESS       1
 
-/* Declared by the reference (minivideo.h:42-52) but unused by its functions. */
+/* minivideo.h:42-52 (names and values kept; no function of the reference returns them: callers test == SUCCESS) */
 typedef enum MiniVideoErrorCodes_e {
-    ERROR_UNKNOWN = 0,
-    ERROR_FILE_ACCESS = 1,
-    ERROR_FILE_EMPTY = 2,
-    ERROR_CONTAINER_UNKNOWN = 3,
-    ERROR_CONTAINER_PARSING = 4,
-    ERROR_CODEC_UNKNOWN = 5,
-    ERROR_DECODER = 6
+    ERROR_UNKNOWN           = 1,
+
+    ERROR_CONTAINER_UNKNOWN = 10,
+    ERROR_CONTAINER_FAILURE = 11,
+
+    ERROR_CODEC_UNKNOWN     = 20,
+    ERROR_CODEC_FAILURE     = 21
 } MiniVideoErrorCodes_e;
 
 /* avcodecs.h:33-66 (values kept) */

@@ -13,6 +13,7 @@
 #include <tmmintrin.h>
 #endif
 
+#include <algorithm>
 #include <vector>
 
 namespace mvexport {
@@ -119,7 +120,14 @@ int write_bmp(const std::string &path, const uint8_t *rgb, int width, int height
     return o.finish();
 }
 
-// stbi_write_tga with stbi_write_tga_with_rle = 1 (the library default), 3 components
+// TGA, type 10 (run-length encoded true colour), bottom row first -- the file stbi_write_tga() makes with its default
+// stbi_write_tga_with_rle = 1 (export.c:726-733 calls it with 3 components).  Byte-exact output needs the library's packet
+// boundaries, which follow from two per-pixel facts of a row, both found here in ONE backward pre-pass:
+//   same[i]  how many pixels from i on equal pixel i                      -> a run packet at i covers min(same[i], 128) pixels
+//   echo[i]  the first k >= i with pixel k == pixel k - 2 (or `width`)    -> a raw packet that starts at i (pixel i + 1
+//            differs from pixel i) ends one pixel BEFORE the first such k >= i + 2 inside its 128-pixel window: the library
+//            compares every new pixel with the one two back, not with its neighbour, and gives the last pixel back
+// The last pixel of a row on its own is a raw packet of one.
 int write_tga(const std::string &path, const uint8_t *rgb, int width, int height)
 {
     File o(path);
@@ -130,39 +138,32 @@ int write_tga(const std::string &path, const uint8_t *rgb, int width, int height
     o.u8(24); o.u8(0);
     std::vector<uint8_t> out;
     out.reserve((size_t)width * 4);
-    auto same = [](const uint8_t *a, const uint8_t *b) { return a[0] == b[0] && a[1] == b[1] && a[2] == b[2]; };
+    std::vector<int> same((size_t)width + 2), echo((size_t)width + 3);
     for (int j = height - 1; j >= 0; j--) {
         const uint8_t *row = rgb + (size_t)j * width * 3;
+        auto equal = [row](int p, int q) { return row[3 * p] == row[3 * q] && row[3 * p + 1] == row[3 * q + 1] && row[3 * p + 2] == row[3 * q + 2]; };
+        same[width] = 0;
+        echo[width] = echo[width + 1] = echo[width + 2] = width;
+        for (int i = width - 1; i >= 0; i--) {
+            same[i] = (i + 1 < width && equal(i, i + 1)) ? same[i + 1] + 1 : 1;
+            echo[i] = (i >= 2 && equal(i, i - 2)) ? i : echo[i + 1];
+        }
         out.clear();
-        int len;
-        for (int i = 0; i < width; i += len) {
-            const uint8_t *begin = row + (size_t)i * 3;
-            bool diff = true;
-            len = 1;
-            if (i < width - 1) {
-                ++len;
-                diff = !same(begin, row + (size_t)(i + 1) * 3);
-                if (diff) {
-                    // raw packet: extend while pixel k differs from pixel k-2 (the library's own rule)
-                    const uint8_t *prev = begin;
-                    for (int k = i + 2; k < width && len < 128; ++k) {
-                        if (!same(prev, row + (size_t)k * 3)) { prev += 3; ++len; }
-                        else { --len; break; }
-                    }
-                } else {
-                    for (int k = i + 2; k < width && len < 128; ++k) {
-                        if (same(begin, row + (size_t)k * 3)) ++len; else break;
-                    }
-                }
-            }
-            if (diff) {
+        for (int i = 0; i < width;) {
+            const int window = std::min(width - i, 128);
+            if (same[i] >= 2) {                       // run packet: count - 129, then the pixel once (B G R)
+                const int n = std::min(same[i], 128);
+                out.push_back((uint8_t)(n - 129));
+                out.push_back(row[3 * i + 2]); out.push_back(row[3 * i + 1]); out.push_back(row[3 * i]);
+                i += n;
+            } else {                                  // raw packet: count - 1, then the pixels
+                const int k = echo[i + 2];
+                const int n = (k < i + window) ? k - i - 1 : window;
                 const size_t at = out.size();
-                out.resize(at + 1 + (size_t)len * 3);
-                out[at] = (uint8_t)(len - 1);
-                swap_rb(&out[at + 1], begin, (size_t)len);
-            } else {
-                out.push_back((uint8_t)(len - 129));
-                out.push_back(begin[2]); out.push_back(begin[1]); out.push_back(begin[0]);
+                out.resize(at + 1 + (size_t)n * 3);
+                out[at] = (uint8_t)(n - 1);
+                swap_rb(&out[at + 1], row + (size_t)i * 3, (size_t)n);
+                i += n;
             }
         }
         o.put(out.data(), out.size());
