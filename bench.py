@@ -320,7 +320,18 @@ def end_to_end(args, params, stream, n_distinct, rec, want_rgb, total, rank, wor
         "d2h": {"busy_s": st["d2h_s"], "share_of_wall": st["d2h_s"] / w, "GB/s": st["d2h_bytes"] / max(st["d2h_s"], 1e-9) / 1e9},
     }
     bound = max(stages, key=lambda k: stages[k]["share_of_wall"])
+    ent_share = stages["entropy_decode_host"]["share_of_wall"]
     return {
+        "host": {
+            "host_cores_visible": cores, "ranks_on_this_host": world, "host_cores_per_rank": cores / world,
+            "entropy_threads_per_rank": threads,
+            "note": "this leg is bound by entropy decoding on the host: N ranks share the host's cores, so its N-GPU curve is a "
+                    "host-core curve (about 16 cores per GPU sustain 3e7 macroblocks/s per GPU on Baseline CAVLC, 1.4e7 on CABAC)"},
+        "wall_not_entropy": {
+            "share_of_wall": max(0.0, 1.0 - ent_share),
+            "what": "the part of the call during which the entropy threads are not all busy: the engine's start (first chunk "
+                    "page-locked and decoded before anything can be uploaded), the drain (upload + kernel + download of the "
+                    "last batch, which nothing overlaps) and the threads that wait for a free chunk while a download is late"},
         "value": total * params.mbs / wall,
         "unit": "macroblocks/s",
         "span": "Annex-B bytes in host memory -> planes" + (" + RGB" if want_rgb else "") + " in page-locked host memory "
@@ -482,6 +493,9 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    # a HOST-side group for waits during which another rank's work runs on this rank's device (rank 0's single-process engine
+    # below): a barrier of the RCCL group is a kernel spinning on every GPU, under the collective watchdog
+    host_pg = dist.new_group(backend="gloo") if (world > 1 and not rehearsal) else None
 
     from minivideo_amd import HotPath
     from minivideo_amd.dist import shard
@@ -539,7 +553,9 @@ def main():
     # ---- the single-process multi-context leg and the cold CLI run (rank 0; the other ranks wait at the barrier below) ----
     multi = cli = None
     if world > 1:
-        dist.barrier()
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()           # rank 0's engine allocates on every device: leave it the room
+        dist.barrier(group=host_pg)
     if rank == 0 and stream is not None:
         n_dev = torch.cuda.device_count() if not rehearsal else 1
         n_ctx = args.engine_contexts if args.engine_contexts >= 0 else (world if world > 1 else 2)
@@ -557,7 +573,7 @@ def main():
             except Exception as ex:   # noqa: BLE001
                 cli = {"error": "%s: %s" % (type(ex).__name__, ex)}
     if world > 1:
-        dist.barrier()   # the other ranks start their kernel leg only when rank 0's engine has left their devices
+        dist.barrier(group=host_pg)   # the other ranks start their kernel leg only when rank 0's engine has left their devices
 
     d_small = torch.from_numpy(rec.reshape(rec.shape[0], -1)).to(dev)
     reps = (F + d_small.shape[0] - 1) // d_small.shape[0]

@@ -16,6 +16,10 @@
  *   - H.264 IDR pictures only, from Annex-B elementary streams (.264/.h264 or a
  *     file starting with an SPS start code) or from the first H.264 video track
  *     of an MP4/MOV file (demuxer/mp4/mp4.c:1950 mp4_fileParse -> sync samples).
+ *   - minivideo_decode() returns SUCCESS when at least one picture file was written and none of the wanted ones is missing
+ *     because a WRITE failed (files are written by a pool of threads behind the decode pipeline; after the first failed
+ *     write -- a full disk -- decoding stops and the call returns FAILURE; the synchronous path used for fewer than four
+ *     pictures decodes a replacement picture instead, like the reference's loop h264.c:173-179);
  * Differences: reconstruction runs on HIP devices (there is no CPU
  * reconstruction path: without a GPU minivideo_decode() returns FAILURE);
  * invalid streams return FAILURE instead of calling exit().

@@ -275,6 +275,7 @@ struct ExportSink {
     int n_writers = 0;
     bool closing = false;
     std::atomic<int> written{0}, write_errors{0};
+    bool stopped_by_write_error = false;
 
     int write_one(const std::string &name, int W, int H, const uint8_t *yuv, const uint8_t *rgb) const
     {
@@ -340,8 +341,10 @@ struct ExportSink {
         name += x.ext;
         const int W = (int)p->width_mbs * 16, H = (int)p->height_mbs * 16;
         if (!x.pool.empty()) {
-            // a write that fails later is reported and counted, but no further picture is decoded in its place (the
-            // synchronous path below does that; so does the reference, whose write errors are as rare as a full disk)
+            // Writers run behind the pipeline, so a write that fails is only known later: no further picture is decoded in
+            // its place (the synchronous path below does that).  Once one has failed -- a full disk does not get better --
+            // decoding stops, and minivideo_decode answers FAILURE unless every wanted file was written (contract: minivideo.h).
+            if (x.write_errors.load() > 0) { x.stopped_by_write_error = true; return -1; }
             {
                 std::unique_lock<std::mutex> l(x.mu);
                 x.cv_room.wait(l, [&] { return x.in_flight < x.max_jobs; });
@@ -496,7 +499,9 @@ minivideo_EXPORT int minivideo_decode(MediaFile_t *m, const char *output_directo
     } es;
     es.th = std::thread([&es] { const double t = wall_s(); es.rc = mvhp_engine_create(nullptr, &es.eng); es.seconds = wall_s() - t; });
 
-    std::shared_ptr<FileBytes> file = take_parsed(m, true);   // (a second minivideo_decode of the same file finds it again)
+    // the bytes minivideo_parse read, once: the cache is emptied here (a second minivideo_decode of the same MediaFile_t reads
+    // the file again -- a 200-MB stream does not stay resident until minivideo_close)
+    std::shared_ptr<FileBytes> file = take_parsed(m, false);
     if (!file) file = read_whole_file(m);
     if (!file) { log_err("Unable to read the media file"); return FAILURE; }
     const FileBytes &buf = *file;
@@ -568,6 +573,7 @@ minivideo_EXPORT int minivideo_decode(MediaFile_t *m, const char *output_directo
                 st.kernel_s, st.d2h_s, st.sink_s);
     }
     if (sink.aborted) return FAILURE;
+    if (sink.write_errors.load() > 0 && sink.written.load() < wanted) return FAILURE;   // files are missing because writes failed
     return sink.written.load() > 0 ? SUCCESS : FAILURE;   // all wanted pictures, or the stream ended after the last good IDR
 }
 

@@ -130,13 +130,16 @@ static bool is_frext_profile(int p)
 
 // scaling_list(), 7.3.2.1.1.1 (the reference's scaling_list_4x4 / _8x8, h264_parameterset.c:723-775, parse the same syntax
 // but store into sps_array[0] and apply no fall-back rule)
-static void parse_scaling_list(BitReader &br, uint8_t *list, int size, uint8_t *state)
+// false: delta_scale outside -128..127 (7.4.2.1.1.1; untrusted input -- a wild se(v) would overflow the sum below) or the
+// list runs off the end of the parameter set
+static bool parse_scaling_list(BitReader &br, uint8_t *list, int size, uint8_t *state)
 {
     int last = 8, next = 8;
     bool use_default = false;
     for (int j = 0; j < size; j++) {
         if (next != 0) {
             const int delta = br.se();
+            if (delta < -128 || delta > 127 || br.overrun()) return false;
             next = (last + delta + 256) % 256;
             use_default = (j == 0 && next == 0);
         }
@@ -144,17 +147,18 @@ static void parse_scaling_list(BitReader &br, uint8_t *list, int size, uint8_t *
         last = list[j];
     }
     *state = use_default ? 2 : 1;
+    return true;
 }
 
-static void parse_scaling_matrix(BitReader &br, ScalingLists &sl, int n_lists)
+static bool parse_scaling_matrix(BitReader &br, ScalingLists &sl, int n_lists)
 {
     sl.present = true;
     for (int i = 0; i < n_lists; i++) {
         sl.state[i] = 0;
         if (!br.bit()) continue;   // seq_ / pic_scaling_list_present_flag[i]
-        if (i < 6) parse_scaling_list(br, sl.l4[i], 16, &sl.state[i]);
-        else parse_scaling_list(br, sl.l8[i - 6], 64, &sl.state[i]);
+        if (!(i < 6 ? parse_scaling_list(br, sl.l4[i], 16, &sl.state[i]) : parse_scaling_list(br, sl.l8[i - 6], 64, &sl.state[i]))) return false;
     }
+    return true;
 }
 
 // Tables 7-3 / 7-4 (zig-zag order, like the transmitted lists)
@@ -238,7 +242,7 @@ int parse_sps(BitReader &br, Sps &s, std::string &err, bool spec)
             // reference envelope: its lists have no fall-back rule and land in sps_array[0] -- refused; by the
             // standard (MVHP_STREAM_SPEC): parsed, h264_parameterset.c:723-736 is the syntax
             if (!spec) { err = "SPS: scaling matrices are not supported"; return RC_UNSUPPORTED; }
-            parse_scaling_matrix(br, s.scaling, 8);
+            if (!parse_scaling_matrix(br, s.scaling, 8)) { err = "SPS: malformed scaling list"; return RC_FAILURE; }
         }
     }
     // h264_parameterset.c:458-465: only Baseline(66), Main(77), High(100)
@@ -310,7 +314,7 @@ int parse_pps(BitReader &br, const Sps *sps_table, Pps &p, std::string &err, boo
         p.transform_8x8_mode = br.bit();
         if (br.bit()) {   // pic_scaling_matrix_present_flag (:904-923: the reference answers UNSUPPORTED)
             if (!spec) { err = "PPS: scaling matrices are not supported"; return RC_UNSUPPORTED; }
-            parse_scaling_matrix(br, p.scaling, 6 + (p.transform_8x8_mode ? 2 : 0));
+            if (!parse_scaling_matrix(br, p.scaling, 6 + (p.transform_8x8_mode ? 2 : 0))) { err = "PPS: malformed scaling list"; return RC_FAILURE; }
         }
         p.second_chroma_qp_index_offset = br.se();
     } else {

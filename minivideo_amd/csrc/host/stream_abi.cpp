@@ -52,13 +52,18 @@ int mvhp_stream::build(std::string &err)
             if (pid < 256 && pps_tab[pid].valid && sps_tab[pps_tab[pid].sps_id].valid) {
                 idr.pps = pps_tab[pid];
                 idr.sps = sps_tab[idr.pps.sps_id];
-                idr.ok = slice_can_hold_picture(idr.sps, s.nal_size);
+                // reference mode: one slice NAL = one picture, and it must be able to hold it.  MVHP_STREAM_SPEC: a picture may
+                // come in many small slices (one per macroblock row of flat content: ten bytes each) -- the guard goes by the
+                // bytes of ALL its slices, once the last one is known (below)
+                idr.nal_bytes = s.nal_size;
+                idr.ok = spec || slice_can_hold_picture(idr.sps, s.nal_size);
                 if (!idr.ok) idr.why = "slice NAL too small for the picture size of its SPS";
                 if (spec && first_mb != 0) {   // a further slice of the previous picture: not a picture of its own
                     if (idrs.empty()) continue;                       // (a stream that starts in the middle of a picture)
                     Idr &pic = idrs.back();
                     if (pic.ok && pic.pps.pps_id != (int)pid) { pic.ok = false; pic.why = "the slices of a picture refer to different picture parameter sets"; }
                     pic.more.push_back(i);
+                    pic.nal_bytes += s.nal_size;
                     continue;
                 }
             } else {
@@ -67,6 +72,12 @@ int mvhp_stream::build(std::string &err)
             idrs.push_back(idr);
         }
     }
+    if (spec)
+        for (Idr &pic : idrs)
+            if (pic.ok && !slice_can_hold_picture(pic.sps, pic.nal_bytes)) {
+                pic.ok = false;
+                pic.why = "the slices of the picture are too small, together, for the picture size of its SPS";
+            }
     return RC_SUCCESS;
 }
 

@@ -13,6 +13,7 @@ struct mvhp_stream {
         h264::Pps   pps;
         bool        ok = false;
         std::string why;
+        size_t      nal_bytes = 0; // MVHP_STREAM_SPEC: NAL bytes of all the picture's slices together (the size guard goes by them)
     };
     const uint8_t *data = nullptr;
     size_t size = 0;

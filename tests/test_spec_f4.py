@@ -134,6 +134,28 @@ def _kat_variants():
     return out
 
 
+def test_a_picture_of_many_small_slices_passes_the_size_guard():
+    """the size guard (a slice NAL must be able to hold the picture its SPS announces: >= 1 payload bit per 8 macroblocks) counts
+    ALL the slices of a picture in spec mode: a full-HD picture of 68 one-row slices of flat content has slice NAL units far
+    below the 128 bytes the whole picture needs; in reference mode, where one slice NAL is one picture, the same
+    NAL units are refused one by one"""
+    W, H = 120, 68
+    stream, packed, _ = gen.make_stream_ex(W, H, 2, seed=9, profile="main", slices=H, dense=False)
+    b = stream.tobytes()
+    starts = [i for i in range(len(b) - 4) if b[i:i + 4] == b"\x00\x00\x00\x01"] + [len(b)]
+    slice_sizes = [starts[k + 1] - starts[k] - 4 for k in range(len(starts) - 1) if (b[starts[k] + 4] & 31) == 5]
+    assert len(slice_sizes) == 2 * H and min(slice_sizes) * 64 < W * H, (len(slice_sizes), min(slice_sizes))
+    with Stream(stream, spec=True) as s:
+        assert s.ok and s.idr_count == 2
+        for k in range(2):
+            rc, rec = s.packed(k)
+            assert rc == 1, s.error()
+            assert np.array_equal(rec.reshape(W * H, 800), packed[k])
+    with Stream(stream) as s:   # reference mode: every slice NAL is a picture of its own, too small for 120 x 68 macroblocks
+        if s.ok:
+            assert all(s.packed(k)[0] != 1 for k in range(s.idr_count))
+
+
 @pytest.mark.parametrize("case", _kat_variants(), ids=lambda c: c[0])
 def test_hand_vectors_on_the_oracle(case):
     _, p, rec, y0, y1, cb0 = case
