@@ -68,10 +68,14 @@ def parse_args():
                     help="pictures of the end-to-end leg, in total over the ranks (-1: 2048 per rank, or P with --strong; 0: skip)")
     ap.add_argument("--e2e-repeats", type=int, default=3, help="timed calls of the end-to-end leg (the median is reported)")
     ap.add_argument("--e2e-batch", type=int, default=0, help="pictures per launch in the end-to-end leg (0: engine default)")
-    ap.add_argument("--placement-trials", type=int, default=3,
-                    help="N = 1 only: re-time the launch on this many sets of ordinarily allocated buffers (reported, not part of value)")
-    ap.add_argument("--ordinary-buffers", action="store_true",
-                    help="allocate the batch buffers the ordinary way instead of mvhp_placed_alloc()")
+    ap.add_argument("--placement-trials", type=int, default=0,
+                    help="N = 1 only: re-time the launch this many times on the OTHER kind of buffers (placed when the timed steps "
+                         "ran on ordinary allocations, and the other way round); reported beside value, never part of it.  A placed "
+                         "set takes one allocation of up to 200 GB (seconds to get, seconds for the driver to clear afterwards)")
+    ap.add_argument("--placed-buffers", action="store_true",
+                    help="the timed steps run on buffers from mvhp_placed_alloc() (records / planes / RGB in three groups of the "
+                         "device's memory regions, DESIGN.md 3); default since round 4: ordinary allocations")
+    ap.add_argument("--ordinary-buffers", action="store_true", help="(the default since round 4; accepted for older scripts)")
     ap.add_argument("--host-threads", type=int, default=0, help="entropy threads per rank (0: host cores / ranks)")
     ap.add_argument("--e2e-placed", action="store_true",
                     help="the end-to-end leg's engine takes its batch buffers from a placed arena (MINIVIDEO_PLACED=1)")
@@ -587,7 +591,7 @@ def main():
     hipc = C.CDLL("libamdhip64.so")
     hipc.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
     placed, buffers_info = None, {"allocator": "torch.empty (hipMalloc)"}
-    if not args.ordinary_buffers:
+    if args.placed_buffers and not args.ordinary_buffers:
         from minivideo_amd import PlacedBuffers, MiniVideoError
         try:
             sizes = [d_packed.numel(), F * params.yuv_bytes] + ([F * params.rgb_bytes] if want_rgb else [])
@@ -677,38 +681,57 @@ def main():
             assert hipc.hipMemcpy(got.ctypes.data, p_rgb + f * params.rgb_bytes, params.rgb_bytes, 2) == 0
             ok = ok and bool(np.array_equal(got, ref_rgb))
     ok = all_ranks_ok(ok, world, dist, dev)
-    # The same launch on ORDINARY allocations, for comparison (reported beside `value`, never part of it): output buffers
-    # allocated the usual way, several times, the earlier ones kept alive so that the next ones land elsewhere.
+    # The same launch on the OTHER kind of buffers, for comparison (reported beside `value`, never part of it): --placement-trials N
     placement = None
-    if world == 1 and args.placement_trials > 0 and placed:
+    if world == 1 and args.placement_trials > 0:
         keep = (p_packed, p_yuv, p_rgb)
-        hold, ms_by_alloc = [], []
-        try:
-            t_packed = torch.empty(mbs_per_step * 800, dtype=torch.uint8, device=dev)
-            assert hipc.hipMemcpy(t_packed.data_ptr(), p_packed, t_packed.numel(), 3) == 0
-            hold.append(t_packed)
-            for _ in range(args.placement_trials):
-                t_yuv = torch.empty(F * params.yuv_bytes, dtype=torch.uint8, device=dev)
-                t_rgb = torch.empty(F * params.rgb_bytes, dtype=torch.uint8, device=dev) if want_rgb else None
-                hold += [t_yuv, t_rgb]
-                p_packed, p_yuv, p_rgb = t_packed.data_ptr(), t_yuv.data_ptr(), (t_rgb.data_ptr() if want_rgb else None)
-                torch.cuda.synchronize(dev)
+        hold, ms_other = [], []
+        other_placed = None
+
+        def time_current():
+            torch.cuda.synchronize(dev)
+            step()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream_t)
+            for _ in range(5):
                 step()
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record(stream_t)
-                for _ in range(5):
-                    step()
-                e1.record(stream_t)
-                torch.cuda.synchronize(dev)
-                ms_by_alloc.append(e0.elapsed_time(e1) / 5)
+            e1.record(stream_t)
+            torch.cuda.synchronize(dev)
+            return e0.elapsed_time(e1) / 5
+        try:
+            if placed:   # timed on placed buffers: ordinary allocations, several sets, the earlier ones kept so that the next land elsewhere
+                t_packed = torch.empty(mbs_per_step * 800, dtype=torch.uint8, device=dev)
+                assert hipc.hipMemcpy(t_packed.data_ptr(), p_packed, t_packed.numel(), 3) == 0
+                hold.append(t_packed)
+                for _ in range(args.placement_trials):
+                    t_yuv = torch.empty(F * params.yuv_bytes, dtype=torch.uint8, device=dev)
+                    t_rgb = torch.empty(F * params.rgb_bytes, dtype=torch.uint8, device=dev) if want_rgb else None
+                    hold += [t_yuv, t_rgb]
+                    p_packed, p_yuv, p_rgb = t_packed.data_ptr(), t_yuv.data_ptr(), (t_rgb.data_ptr() if want_rgb else None)
+                    ms_other.append(time_current())
+            else:        # timed on ordinary allocations: one placed set
+                from minivideo_amd import PlacedBuffers, MiniVideoError
+                sizes = [mbs_per_step * 800, F * params.yuv_bytes] + ([F * params.rgb_bytes] if want_rgb else [])
+                other_placed = PlacedBuffers(local_rank, sizes)
+                assert hipc.hipMemcpy(other_placed.ptrs[0], p_packed, sizes[0], 3) == 0
+                p_packed, p_yuv, p_rgb = other_placed.ptrs[0], other_placed.ptrs[1], (other_placed.ptrs[2] if want_rgb else None)
+                for _ in range(args.placement_trials):
+                    ms_other.append(time_current())
             hot.sync_check(sp)
-        except RuntimeError:   # not enough memory beside the arena for (all of) them
-            pass
+        except (RuntimeError, Exception) as ex:   # noqa: BLE001 -- not enough memory beside the batch, or no arena to be had
+            ms_other.append(None)
+            placement_note = "%s: %s" % (type(ex).__name__, ex)
+        else:
+            placement_note = None
         p_packed, p_yuv, p_rgb = keep
-        placement = {"ms_per_step_on_ordinary_allocations": [round(v, 3) for v in ms_by_alloc],
-                     "ms_per_step_timed": round(ms_recon + ms_color, 3),
-                     "note": "timed steps: buffers from mvhp_placed_alloc; the others: torch.empty (as many sets as fit beside the arena), 5 launches each"}
+        placement = {"ms_per_step_timed": round(ms_recon + ms_color, 3),
+                     "timed_on": "mvhp_placed_alloc" if placed else "ordinary allocations",
+                     ("ms_per_step_on_ordinary_allocations" if placed else "ms_per_step_on_placed_buffers"): [None if v is None else round(v, 3) for v in ms_other],
+                     "placed_set_up_s": None if other_placed is None else round(other_placed.seconds, 2),
+                     "note": placement_note or "5 launches per figure; the other kind of buffers is never part of `value`"}
         hold.clear()
+        if other_placed is not None:
+            other_placed.close()
         t_packed = t_yuv = t_rgb = None
     del d_packed, d_yuv, d_rgb
     hot.close()

@@ -8,6 +8,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <string>
 
 #include "decode_engine.h"
@@ -685,7 +686,24 @@ void *eng_placed_alloc(DevCtx *d, int sets, const size_t bytes[4], void **ptrs)
     static const uint8_t any_group[4] = {1, 0, 0, 0};   // {compact, records, planes, RGB}
     void *arena = nullptr;
     int found = 0;
-    if (mvhp_placed_alloc_sets(d->c->device, sets, 4, bytes, any_group, 0, ptrs, &arena, nullptr, &found) != MVHP_SUCCESS) return nullptr;
+    // an arena sized from the need, not "everything that is free": twice the buffers (room to choose blocks of the
+    // right group) + 16 GB, inside the library's cap -- what the device keeps free stays available to ordinary allocations
+    // (another picture shape, a second context on the device)
+    const size_t blk = (size_t)4 << 30;   // (placement.hip hands out runs of 4-GB blocks)
+    size_t need = 0;
+    for (int i = 0; i < 4; i++) need += (bytes[i] + blk - 1) / blk * blk;
+    need *= (size_t)sets;
+    size_t want = need + need / 2 + ((size_t)16 << 30);
+    size_t cap = (size_t)200 << 30;
+    if (const char *e = getenv("MVHP_PLACED_ARENA_GB")) { const long gb = atol(e); if (gb >= 8 && gb <= 256) cap = (size_t)gb << 30; }
+    size_t fr = 0, tot = 0;
+    if (hipSetDevice(d->c->device) == hipSuccess && hipMemGetInfo(&fr, &tot) == hipSuccess) {
+        const size_t reserve = (size_t)24 << 30;
+        cap = std::min(cap, fr > reserve ? fr - reserve : (size_t)0);
+    }
+    want = std::min(want, cap);
+    if (want < need) return nullptr;
+    if (mvhp_placed_alloc_sets(d->c->device, sets, 4, bytes, any_group, want, ptrs, &arena, nullptr, &found) != MVHP_SUCCESS) return nullptr;
     return arena;
 }
 

@@ -495,7 +495,13 @@ minivideo_EXPORT int minivideo_decode(MediaFile_t *m, const char *output_directo
         std::thread th;
         bool joined = false;
         void join() { if (!joined) { th.join(); joined = true; } }
-        ~EngineStart() { join(); if (eng) mvhp_engine_destroy(eng); }
+        ~EngineStart()
+        {
+            join();
+            const double t = wall_s();
+            if (eng) mvhp_engine_destroy(eng);
+            if (getenv("MINIVIDEO_STATS")) fprintf(stderr, "[minivideo] engine torn down in %.3f s\n", wall_s() - t);
+        }
     } es;
     es.th = std::thread([&es] { const double t = wall_s(); es.rc = mvhp_engine_create(nullptr, &es.eng); es.seconds = wall_s() - t; });
 

@@ -412,6 +412,16 @@ bool Engine::ensure_devbuf(Ctx &c, DevBuf &b, const Batch &bt, std::string &err)
         if (c.arena) {
             c.arena_pictures = n;
             c.arena_params = bt.params;
+            {   // what is left of the device now bounds every later ordinary allocation (a batch of another shape, another
+                // context on this device): the budgets of all contexts on it are taken again
+                const size_t free_b = api_.dev_free_bytes(c.dev);
+                for (Ctx &o : ctx_) {
+                    if (o.device != c.device) continue;
+                    int sharers = 0;
+                    for (const Ctx &j : ctx_) sharers += j.device == c.device;
+                    o.mem_budget = std::min(o.mem_budget, free_b / 2 / (size_t)o.n_bufs / (size_t)std::max(1, sharers));
+                }
+            }
             for (int k = 0; k < 3; k++) {
                 DevBuf &d = c.bufs[k];
                 // (ordinary buffers from an earlier call of another shape are released; none is in use: the first batch)

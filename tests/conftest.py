@@ -22,14 +22,3 @@ def hot(request):
     h.set_layout(request.param)
     yield h
     h.close()
-
-
-def pytest_collection_modifyitems(config, items):
-    """The placement tests go FIRST.  They hold and free arenas of up to 200 GB; the driver wipes released device memory in the
-    background (about 3 s for 200 GB), and a process that exits with that still pending makes the NEXT process on the device --
-    the driver's smoke() and bench.py -- wait for it in its first allocations (a 3.8-s "cold call", profiles/r03m_base1080_bench.json).
-    At the front of the suite the wipe is long over when pytest exits."""
-    front = [it for it in items if "test_gpu_placement" in it.nodeid]
-    if front:
-        rest = [it for it in items if "test_gpu_placement" not in it.nodeid]
-        items[:] = front + rest

@@ -132,7 +132,8 @@ def test_cli_file_writers(tmp_path, writers, fmt):
 
 
 def test_cli_unwritable_directory_fails(tmp_path):
-    """every write fails (read-only working directory): the pool reports each file and the call fails, as the synchronous path does"""
+    """every write fails (read-only working directory): the pool reports the files it tried, decoding stops once a failure is
+    known (a full disk does not get better) and the call fails (minivideo.h: the contract of minivideo_decode)"""
     import stat
     stream, _ = gen.make_stream(6, 4, 8, seed=62, profile="baseline")
     (tmp_path / "in").mkdir()
@@ -145,7 +146,7 @@ def test_cli_unwritable_directory_fails(tmp_path):
         if os.access(ro, os.W_OK):
             pytest.skip("running as a user that ignores directory permissions")
         r = subprocess.run([CLI, "-i", str(src), "-f", "yuv420", "-n", "8"], cwd=ro, capture_output=True, text=True, timeout=120)
-        assert r.stderr.count("Unable to write") == 8, r.stderr
+        assert 1 <= r.stderr.count("Unable to write") <= 8, r.stderr
         assert "decode did not succeed" in r.stderr, (r.stdout, r.stderr)
     finally:
         os.chmod(ro, stat.S_IRWXU)

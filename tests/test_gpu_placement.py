@@ -12,6 +12,14 @@ pytestmark = pytest.mark.gpu
 GB = 1 << 30
 
 
+@pytest.fixture(autouse=True)
+def _small_arenas(monkeypatch):
+    """No test here needs more than 48 GB: an arena "as large as is free" (200 GB) takes seconds to get, and the driver wipes it
+    in the background when it is released -- the NEXT process on the device (smoke(), bench.py) would pay for that in its
+    first allocations.  (Round 3 ran these tests first for that reason; with the cap the order does not matter.)"""
+    monkeypatch.setenv("MVHP_PLACED_ARENA_GB", "48")
+
+
 def _hip():
     h = C.CDLL("libamdhip64.so")
     h.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
@@ -84,13 +92,27 @@ def test_placed_sets_are_disjoint_and_a_group_per_buffer():
     L.mvhp_placed_alloc_sets.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_uint8), C.c_size_t,
                                          C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.mvhp_placed_free.argtypes = [C.c_void_p]
-    sizes = [1 * GB, 5 * GB, 2 * GB, 4 * GB + 1]
+    sizes = [1 * GB, 3 * GB, 2 * GB, 2 * GB + 1]
     arr = (C.c_size_t * 4)(*sizes)
     anyg = (C.c_uint8 * 4)(1, 0, 0, 0)
     ptrs, arena, gof, gf = (C.c_void_p * 12)(), C.c_void_p(), (C.c_int * 4)(), C.c_int()
     rc = L.mvhp_placed_alloc_sets(0, 3, 4, arr, anyg, 0, ptrs, C.byref(arena), gof, C.byref(gf))
     if rc != 1:
-        pytest.skip("the arena shows fewer than three groups with room on this device (callers fall back to ordinary allocations)")
+        # a 48-GB arena that does not show three groups with room for three sets: the documented answer is a clean failure --
+        # nothing is handed out, nothing stays allocated -- and the caller's ordinary allocations of the same sizes work
+        assert rc == 0 and not arena.value
+        hip = _hip()
+        hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+        hip.hipFree.argtypes = [C.c_void_p]
+        held = []
+        for _ in range(3):
+            for sz in sizes:
+                q = C.c_void_p()
+                assert hip.hipMalloc(C.byref(q), sz) == 0 and q.value
+                held.append(q)
+        for q in held:
+            assert hip.hipFree(q) == 0
+        return
     try:
         spans = sorted((int(ptrs[s * 4 + i]), int(ptrs[s * 4 + i]) + sizes[i]) for s in range(3) for i in range(4))
         assert all(spans[k][1] <= spans[k + 1][0] for k in range(11)), spans
@@ -120,9 +142,9 @@ def test_engine_on_a_placed_arena_matches_the_oracle():
         rc2, st2 = eng.decode(s.h, list(range(F - 1, -1, -1)), want_rgb=True)     # the arena is kept: nothing is allocated again
     eng.close()
     assert rc == 1 and st["pictures_ok"] == F and rc2 == 1 and st2["pictures_ok"] == F
-    if not st["placed_buffers"]:
-        pytest.skip("no placed arena on this device (too few groups / memory): the engine used ordinary allocations")
-    assert st2["placed_buffers"] == 1 and st2["dev_alloc_bytes"] == 0
+    if st["placed_buffers"]:
+        assert st2["placed_buffers"] == 1 and st2["dev_alloc_bytes"] == 0
+    # (no arena to be had on this device -- too few groups with room: the engine ran on ordinary allocations; same pictures)
     for k in range(F):
         ref_yuv, ref_rgb = loader.recon(p, packed[k], 1, want_rgb=True)
         assert got[k][0] == 1 and np.array_equal(got[k][1], ref_yuv) and np.array_equal(got[k][2], ref_rgb), k
