@@ -68,7 +68,7 @@ def parse_args():
                     help="pictures of the end-to-end leg, in total over the ranks (-1: 2048 per rank, or P with --strong; 0: skip)")
     ap.add_argument("--e2e-repeats", type=int, default=3, help="timed calls of the end-to-end leg (the median is reported)")
     ap.add_argument("--e2e-batch", type=int, default=0, help="pictures per launch in the end-to-end leg (0: engine default)")
-    ap.add_argument("--placement-trials", type=int, default=0,
+    ap.add_argument("--placement-trials", type=int, default=1,
                     help="N = 1 only: re-time the launch this many times on the OTHER kind of buffers (placed when the timed steps "
                          "ran on ordinary allocations, and the other way round); reported beside value, never part of it.  A placed "
                          "set takes one allocation of up to 200 GB (seconds to get, seconds for the driver to clear afterwards)")

@@ -29,9 +29,13 @@ def _newer(target, sources):
     return any(os.path.getmtime(s) > t for s in sources)
 
 
+COMMANDS = []   # every compiler / linker command this process has run (build_report())
+
+
 def _run(cmd):
     print("+", " ".join(cmd), flush=True)
     subprocess.check_call(cmd)
+    COMMANDS.append(cmd)
 
 
 def build_product(force=False):
@@ -123,6 +127,15 @@ def build_all(force=False):
     build_cli(force)
     build_generator(force)
     build_oracle(force)
+    return build_report(force)
+
+
+def build_report(force=False):
+    """what this process's build did: compiled (how many commands) or reused the binaries in the tree"""
+    return {"build_mode": "forced rebuild" if force else "incremental (only what is older than its sources)",
+            "build_exercised": len(COMMANDS) > 0, "commands_run": len(COMMANDS),
+            "hip_objects_compiled": sum(1 for c in COMMANDS if "--offload-arch=gfx950" in c and "-c" in c),
+            "artifacts": [os.path.relpath(p, ROOT) for p in (LIB, CLI, GEN, ORACLE) if os.path.exists(p)]}
 
 
 if __name__ == "__main__":
