@@ -199,21 +199,18 @@ MVHP_EXPORT int mvhp_set_fused_color(mvhp_ctx_t *c, int on)
 //   Few pictures: ONE picture (one group of four) spread over several workgroups, bands of four macroblock rows each
 //   ("wide" forms: SURVEY 7 step 5's "grid = F x PicHeightInMbs wavefronts"); many pictures: one workgroup per group of
 //   four / eight.  Measured on 1080p Baseline (tools/layout_crossover.py, profiles/r04*_crossover_*.log; ms per launch):
-//     pictures        4     16     64    128    256    512    768   1024
-//     rows          2.47   2.49   2.53   2.55   2.58   5.00     -    8.86     one workgroup per picture (round 1-3)
-//     quad          3.99   4.00   4.00   4.02   4.05   4.16   4.32   4.48     ... per four pictures
-//     wide          1.01   1.02   1.28   1.61   2.44   4.40     -    8.51     one picture in 17 bands
-//     quad_wide       -    1.38   1.45   1.65   2.00   2.89   3.91   4.96     four pictures in 17 bands
-//     pipe (4 rows)  0.73 (one picture)  0.98   1.20   1.51   2.29   3.97     four pictures in 17 bands, three waves per row
-//   so: wide up to CUs / 2 pictures of 68 rows, quad_wide up to 3.5 x CUs, then the round model of rounds 2-3 between the
-//   four- and the eight-picture kernel.  The thresholds scale with the rows of a picture (what fills the chip is row-waves).
-//   High profile (Intra8x8 in the mix; the same table in profiles/r04d_crossover_high*.log): wide 1.07 / 1.37 / 1.69 / 2.58 /
-//   4.61 ms at 16 / 64 / 128 / 256 / 512 pictures against quad_wide 1.91 / 2.05 / 2.39 / 2.84 / 3.95 -- the four pictures of a
-//   wavefront run their three luma paths one after the other -- so wide up to 1.3 x CUs pictures there.
-//   The three-waves-per-row form (pipe) is within 8 % of wide on Baseline and 20-30 % behind it on High: the step is the
-//   prediction chain, LDS round trip by LDS round trip, and taking residuals and write-out off it shortens it less than four
-//   pictures in lock step lengthen it.  It wins where the four quarters of a wavefront hold the SAME picture (a short group of
-//   up to three pictures: no divergence), 0.73 against 1.00 ms -- the single-thumbnail case.
+//     pictures        1     16     64    128    256    512    768   1024
+//     rows          2.45   2.49   2.53   2.55   2.58   5.00     -    8.86     one workgroup per picture (rounds 1-3)
+//     quad          2.95   4.00   4.00   4.02   4.05   4.16   4.32   4.5-5.4  ... per four pictures
+//     wide          1.00   1.02   1.29   1.59   2.42   4.34     -    8.51     one picture in 17 bands
+//     quad_wide     1.06   1.38   1.46   1.69   2.01   2.85   3.91   4.96     four pictures in 17 bands
+//     pipe          0.58   0.78   0.97   1.24   1.90   3.30   4.74   6.23     ... three waves per row: residuals / luma / chroma + output
+//   so, Baseline: pipe up to CUs pictures of 68 rows, quad_wide up to 3.5 x CUs, then the round model of rounds 2-3 between
+//   the four- and the eight-picture kernel.  The thresholds scale with the rows of a picture (what fills the chip is row-waves).
+//   High profile (Intra8x8 in the mix; profiles/r04f_crossover_high*.log): wide 1.06 / 1.35 / 1.69 / 2.58 / 4.61 ms at 16 / 64 /
+//   128 / 256 / 512 pictures, pipe 1.18 / 1.45 / 1.82, quad_wide 1.91 / 2.05 / 2.39 / 2.84 / 3.95 -- the four pictures of a
+//   wavefront run their three luma paths one after the other -- so there: wide up to 1.3 x CUs pictures, then quad_wide.
+//   Up to three pictures the quarters of a wavefront hold the SAME picture (no divergence): pipe on every profile (0.58 / 0.67 ms).
 static int pick_layout(const mvhp_ctx *c, const mvhp_stream_params_t *p, int n_frames)
 {
     int layout = c->layout;
@@ -225,7 +222,8 @@ static int pick_layout(const mvhp_ctx *c, const mvhp_stream_params_t *p, int n_f
         const double cus = (double)c->n_cus;
         const double row_waves = (double)n_frames * (double)p->height_mbs;
         const bool may8 = (p->flags & MVHP_PARAM_MAY_HAVE_8X8) != 0;
-        if (n_frames <= 3 && mvhp::recon_pipe_lds_bytes((int)p->width_mbs, 4) <= c->max_lds) {
+        const bool pipe_fits = mvhp::recon_pipe_lds_bytes((int)p->width_mbs, 1) <= c->max_lds;
+        if (pipe_fits && (n_frames <= 3 || (!may8 && row_waves <= 68.0 * cus))) {
             layout = MVHP_LAYOUT_PIPE;
         } else if (row_waves <= (may8 ? 90.0 : 34.0) * cus) {
             layout = MVHP_LAYOUT_WIDE;

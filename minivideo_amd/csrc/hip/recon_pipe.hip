@@ -12,10 +12,11 @@
 // neighbours.  Here a row has
 //   F  the residual wave: reads the packed records (the only wave that loads from HBM), dequantises, inverse-transforms and
 //      leaves header + residuals of macroblock x in slot x % 2 of a ring in LDS -- no dependency on anything but a free slot;
-//   K  the prediction wave: waits for the row above (or the seam), predicts chroma and luma into tile x % 2, adds the
-//      residuals, hands the bottom row / right column on, publishes -- the chain every other row waits for, and nothing else;
-//   O  the output wave: takes finished tiles, parks them in the four-macroblock strip, converts to RGB, stores (the only wave
-//      that writes HBM).
+//   K  the luma wave: waits for the row above (or the seam), predicts luma into tile x % 2, adds the residuals, hands the
+//      bottom row / right column on, publishes -- the chain every other row waits for, and nothing else;
+//   O  the chroma + output wave: chroma prediction is independent of luma and needs no up-right neighbour, so it runs here,
+//      one macroblock behind the row above's O; then the finished macroblock is parked in the four-macroblock strip,
+//      converted to RGB and stored (the only wave that writes HBM).
 // The three run on one SIMD (waves w, w + 4, w + 8 of the workgroup), so K's LDS round trips are filled with F's and O's
 // arithmetic.  Four pictures per wavefront, 16 lanes each, exactly as recon_quad.hip (lane j owns luma 4x4 block j and, for
 // j < 8, chroma block j); a workgroup = one band of four rows = 12 wavefronts; bands, tickets and seams as
@@ -34,6 +35,13 @@ namespace mvhp {
 #define MVHP_UNROLL(n) MVHP_PRAGMA_(unroll n)
 
 constexpr int PIPE_ROWS_MAX = 4;    // rows per band = rows per workgroup: 1, 2 or 4 (three wavefronts each)
+#ifndef MVHP_PIPE_SLOTS
+#define MVHP_PIPE_SLOTS 4           // F -> K / O ring: F may run this many macroblocks ahead of the slower of K and O
+#endif
+#ifndef MVHP_PIPE_TILES
+#define MVHP_PIPE_TILES 3           // K -> O ring: K may run this many macroblocks ahead of O (whose strip flush is bursty)
+#endif
+constexpr int NSLOT = MVHP_PIPE_SLOTS, NTILE = MVHP_PIPE_TILES;
 
 // F -> K: one macroblock of one picture
 struct __attribute__((aligned(16))) PSlot {
@@ -44,31 +52,49 @@ struct __attribute__((aligned(16))) PSlot {
 };
 static_assert(sizeof(PSlot) == 800, "PSlot layout");
 
-// K -> O: the macroblock under construction / just finished (as QLds::T, QLds::TC)
+// K -> O: the luma of the macroblock under construction / just finished (as QLds::T)
 struct __attribute__((aligned(16))) PTile {
-    uint8_t T[17 * 32 + 16];   // luma: row 0 = top neighbours (bytes 16..31, up-right 32..39), byte 15 of rows 0..16 = corner / left column
-    uint8_t TC[2][9 * 16];     // chroma: row 0 = top; byte 7 = corner / left column, 8..15 samples
+    uint8_t T[17 * 32 + 16];   // row 0 = top neighbours (bytes 16..31, up-right 32..39), byte 15 of rows 0..16 = corner / left column
 };
-static_assert(sizeof(PTile) == 848, "PTile layout");
+static_assert(sizeof(PTile) == 560, "PTile layout");
 
 struct __attribute__((aligned(16))) PRow {   // one macroblock row of the band, four pictures
-    PSlot   slot[2][4];
+    PSlot   slot[NSLOT][4];
     int32_t scr[4][128];       // F: Intra8x8 transpose scratch
-    PTile   tile[2][4];
+    PTile   tile[NTILE][4];
     uint8_t Lcol[4][16];       // K: compact left neighbour column (luma)
-    uint8_t LcolC[4][2][8];
     uint8_t E8[4][32];         // K: filtered Intra8x8 edge
+    uint8_t TC[4][2][9 * 16];  // O: chroma tiles (as QLds::TC): row 0 = top; byte 7 = corner / left column, 8..15 samples
+    uint8_t LcolC[4][2][8];    // O: compact left neighbour columns (Cb, Cr)
     uint8_t SC[4][2][8 * 24];  // O: chroma rows of the three parked macroblocks of a strip
 };
 
 struct __attribute__((aligned(16))) PCtl {
     int f_done[PIPE_ROWS_MAX];     // macroblocks whose residuals F has left in the ring
     int k_done[PIPE_ROWS_MAX];     // macroblocks K has finished (what the row below and O wait for; frees F's slot)
-    int o_done[PIPE_ROWS_MAX];     // macroblocks O has taken out of their tile (frees K's tile)
+    int o_done[PIPE_ROWS_MAX];     // macroblocks O has taken out of their tile and whose ring slot it has read (frees both)
+    int c_done[PIPE_ROWS_MAX];     // macroblocks whose chroma O has finished (what the row below's O waits for)
     int abort_flag;
     int unit;
     int pad[2];
 };
+static_assert(sizeof(PCtl) % 16 == 0, "PCtl layout");
+
+#if defined(MVHP_PIPE_STAMPS)
+// measurement build (tools/build_variant.sh pstamps -DMVHP_PIPE_STAMPS; tools/pipe_stamps.py): where a K wave's step goes --
+// the shader clock at section boundaries, summed over the launch.  [section][0] = cycles, [section][1] = visits
+__device__ unsigned long long g_pipe_stamps[16][2];
+#define PSTAMP(k)                                                                                  \
+    do {                                                                                           \
+        const unsigned long long t_ = __builtin_amdgcn_s_memtime();                                \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                         \
+        ps_acc[k] += t_ - ps_prev;                                                                 \
+        ps_n[k]++;                                                                                 \
+        ps_prev = t_;                                                                              \
+    } while (0)
+#else
+#define PSTAMP(k)
+#endif
 
 // spin until *ctr >= need; false = give up (error word set)
 __device__ __forceinline__ bool pipe_wait(const int *ctr, int need, PCtl &C, uint32_t *err, int lane)
@@ -117,7 +143,7 @@ __global__ __launch_bounds__(PIPE_ROWS * 3 * 64) void recon_pipe_kernel(ReconArg
     for (int i = threadIdx.x; i < 2 * 9 * 16; i += NT)
         B.tap4[i] = tap4_entry((i >> 4) % 9, i & 3, (i >> 2) & 3, i >= 9 * 16);
     for (int i = threadIdx.x; i < 9 * 64; i += NT) B.tap8[i] = tap8_entry(i >> 6, i & 7, (i >> 3) & 7);
-    if (threadIdx.x < PIPE_ROWS_MAX) { C.f_done[threadIdx.x] = 0; C.k_done[threadIdx.x] = 0; C.o_done[threadIdx.x] = 0; }
+    if (threadIdx.x < PIPE_ROWS_MAX) { C.f_done[threadIdx.x] = 0; C.k_done[threadIdx.x] = 0; C.o_done[threadIdx.x] = 0; C.c_done[threadIdx.x] = 0; }
     if (threadIdx.x == 16) C.abort_flag = 0;
     __syncthreads();
 
@@ -170,7 +196,7 @@ __global__ __launch_bounds__(PIPE_ROWS * 3 * 64) void recon_pipe_kernel(ReconArg
             const int q = lane >> 4, j = lane & 15;
             const int4 cH0 = nH0, cH1 = nH1, cLA = nLA, cLB = nLB, cCA = nCA, cCB = nCB;
             if (mbx + 1 < W) load_rec(mbx + 1);
-            PSlot &S = R.slot[mbx & 1][q];
+            PSlot &S = R.slot[mbx % NSLOT][q];
             int32_t *scr = R.scr[q];
             const uint32_t h0 = (uint32_t)cH0.x, nz = (uint32_t)cH0.z;
             const int kind = h0 & 255;
@@ -183,8 +209,9 @@ __global__ __launch_bounds__(PIPE_ROWS * 3 * 64) void recon_pipe_kernel(ReconArg
             const bool any_l = __builtin_amdgcn_ballot_w64(need_l) != 0;
             const bool any_c = __builtin_amdgcn_ballot_w64(need_c) != 0;
 
-            // the slot is free once K has finished macroblock mbx - 2
-            if (!pipe_wait(&C.k_done[r], mbx - 1, C, a.err, lane)) return;
+            // the slot is free once K and O have finished with macroblock mbx - NSLOT
+            if (!pipe_wait(&C.k_done[r], mbx - NSLOT + 1, C, a.err, lane)) return;
+            if (!pipe_wait(&C.o_done[r], mbx - NSLOT + 1, C, a.err, lane)) return;
 
             int r2[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // luma block j: packed int16 pairs, row-major
             int c2[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // chroma block j (j < 8)
@@ -362,8 +389,8 @@ __global__ __launch_bounds__(PIPE_ROWS * 3 * 64) void recon_pipe_kernel(ReconArg
 
     if (role == 1) {
         // =========================================================================================================
-        // K: prediction + residual add (h264_intra_prediction.c:112-2564, transform*_luma / _chroma of h264_transform.c),
-        //    neighbour state, the row dependency
+        // K: luma prediction + residual add (h264_intra_prediction.c:112-2141, transform*_luma of h264_transform.c), luma neighbour
+        //    state, the row dependency
         // =========================================================================================================
         const bool seam_in = (r == 0) && band > 0;                       // top neighbours of this row come from the seam above
         const bool seam_out = (r == PIPE_ROWS - 1) && (row + 1 < H);     // this row's bottom samples feed the seam below
@@ -372,30 +399,34 @@ __global__ __launch_bounds__(PIPE_ROWS * 3 * 64) void recon_pipe_kernel(ReconArg
         unsigned long long *seam_wr = seam_out ? a.seam + ((size_t)grp * 4 * (bands - 1) + band) * W * SEAM_GRANULES : nullptr;
         unsigned long long seam_pend = 0;
         __builtin_amdgcn_s_setprio(2);   // the chain every other row waits for
+#if defined(MVHP_PIPE_STAMPS)
+        unsigned long long ps_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ps_prev = __builtin_amdgcn_s_memtime();
+        unsigned ps_n[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
 #pragma unroll 1
         for (int mbx = 0; mbx < W; mbx++) {
             int lane = lane_c;
             asm volatile("" : "+v"(lane));
             const int q = lane >> 4, j = lane & 15;
-            const PSlot &S = R.slot[mbx & 1][q];
-            PTile &Tl = R.tile[mbx & 1][q];
-            PTile &Tn = R.tile[(mbx + 1) & 1][q];    // where the next macroblock of the row will be built
+            const PSlot &S = R.slot[mbx % NSLOT][q];
+            PTile &Tl = R.tile[mbx % NTILE][q];
+            PTile &Tn = R.tile[(mbx + 1) % NTILE][q];    // where the next macroblock of the row will be built
             uint8_t *T = Tl.T;
             uint8_t *line_y = lines + (size_t)q * W * 32;
-            uint8_t *line_cb = line_y + W * 16;
-            uint8_t *line_cr = line_cb + W * 8;
             const bool A = mbx > 0, Cav = Bv && (mbx < W - 1), D = A && Bv;
 
             if (seam_in && (mbx & 1) == 0) {
-                // Macroblocks mbx and mbx + 1 read columns <= mbx + 2 of the row above.  The first step of a row fetches columns
-                // 0..3 now (two rounds); every later even step finds (mbx + 1, mbx + 2) asked for two steps ago, and asks for
-                // (mbx + 3, mbx + 4).  Lane j of a quarter: column c0 + (j >> 3), granule j & 7 (0-3 luma dwords, 4-5 Cb, 6-7 Cr).
-                const int g = j & 7;
+                // Macroblocks mbx and mbx + 1 read luma columns <= mbx + 2 of the row above.  The first step of a row fetches
+                // columns 0..3 now (two rounds); every later even step finds (mbx + 1, mbx + 2) asked for two steps ago, and asks
+                // for (mbx + 3, mbx + 4).  Lane j < 8 of a quarter: column c0 + (j >> 2), luma granule j & 3 (the chroma granules
+                // 4-7 of a column are O's).
+                const int g = j & 3;
                 const uint32_t lo = qf * seam_pic + (uint32_t)g;
                 int c0 = mbx ? mbx + 1 : 0;
                 for (int round = mbx ? 1 : 0; round < 2; round++, c0 += 2) {
-                    const int col = c0 + (j >> 3);
-                    const bool act = col < W;
+                    const int col = c0 + ((j >> 2) & 1);
+                    const bool act = (j < 8) && (col < W);
                     const unsigned long long *src = seam_rd + lo + (uint32_t)((act ? col : 0) * SEAM_GRANULES);
                     unsigned long long v = seam_pend;
                     if (mbx == 0) v = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -411,93 +442,39 @@ __global__ __launch_bounds__(PIPE_ROWS * 3 * 64) void recon_pipe_kernel(ReconArg
                         }
                         v = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
-                    if (act) {
-                        uint8_t *dst = (g < 4) ? &line_y[col * 16 + g * 4] : (g < 6) ? &line_cb[col * 8 + (g - 4) * 4] : &line_cr[col * 8 + (g - 6) * 4];
-                        *reinterpret_cast<uint32_t *>(dst) = (uint32_t)v;
-                    }
+                    if (act) *reinterpret_cast<uint32_t *>(&line_y[col * 16 + g * 4]) = (uint32_t)v;
                 }
-                const int ncol = mbx + 3 + (j >> 3);
-                if (ncol < W) seam_pend = __hip_atomic_load(seam_rd + lo + (uint32_t)(ncol * SEAM_GRANULES), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const int ncol = mbx + 3 + ((j >> 2) & 1);
+                if (j < 8 && ncol < W) seam_pend = __hip_atomic_load(seam_rd + lo + (uint32_t)(ncol * SEAM_GRANULES), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 WAVE_SYNC();
             }
 
-            // the tile is free once O has taken macroblock mbx - 2 out of it; the residuals of mbx must be in the ring
-            if (!pipe_wait(&C.o_done[r], mbx - 1, C, a.err, lane)) return;
+            PSTAMP(0);   // seam
+            // the tile is free once O has taken macroblock mbx - NTILE out of it; the residuals of mbx must be in the ring
+            // (the left column / corner K wrote into this tile one step ago are not O's bytes)
+            if (!pipe_wait(&C.o_done[r], mbx - NTILE + 1, C, a.err, lane)) return;
             if (!pipe_wait(&C.f_done[r], mbx + 1, C, a.err, lane)) return;
+            PSTAMP(1);   // waits for O and F
             const int4 hA = *reinterpret_cast<const int4 *>(&S.hdr[0]);
             const int4 hB = *reinterpret_cast<const int4 *>(&S.hdr[4]);
             const uint32_t h0 = (uint32_t)hA.x, h1 = (uint32_t)hA.y;
             const uint32_t m0 = (uint32_t)hA.w, m1 = (uint32_t)hB.x, m2 = (uint32_t)hB.y, m3 = (uint32_t)hB.z;
             const int kind = h0 & 255;
-            const int cmode = (h0 >> 24) & 255, i16mode = h1 & 255;
+            const int i16mode = h1 & 255;
             const int xO = (((j >> 2) & 1) << 3) | ((j & 1) << 2);
             const int yO = ((j >> 3) << 3) | (((j >> 1) & 1) << 2);
 
             // wait for the row above: needs columns <= min(mbx+1, W-1); then fetch the top neighbours
             if (Bv) {
                 if (!seam_in && !pipe_wait(&C.k_done[r - 1], min(mbx + 2, W), C, a.err, lane)) return;
-                // lanes 0-3 luma top, 4-5 luma up-right (when C), 6-7 Cb top, 8-9 Cr top: one dword each
-                if (j < 10 && (Cav || (j >> 1) != 2)) {
-                    uint8_t *dst;
-                    const uint8_t *src;
-                    if (j < 4) { dst = &T[16 + j * 4]; src = &line_y[mbx * 16 + j * 4]; }
-                    else if (j < 6) { dst = &T[32 + (j - 4) * 4]; src = &line_y[mbx * 16 + 16 + (j - 4) * 4]; }
-                    else if (j < 8) { dst = &Tl.TC[0][8 + (j - 6) * 4]; src = &line_cb[mbx * 8 + (j - 6) * 4]; }
-                    else { dst = &Tl.TC[1][8 + (j - 8) * 4]; src = &line_cr[mbx * 8 + (j - 8) * 4]; }
-                    *reinterpret_cast<uint32_t *>(dst) = *reinterpret_cast<const uint32_t *>(src);
+                // lanes 0-3 luma top, 4-5 luma up-right (when C): one dword each
+                if (j < 6 && (Cav || j < 4)) {
+                    uint8_t *dst = (j < 4) ? &T[16 + j * 4] : &T[32 + (j - 4) * 4];
+                    *reinterpret_cast<uint32_t *>(dst) = *reinterpret_cast<const uint32_t *>(&line_y[mbx * 16 + j * 4]);
                 }
             }
             WAVE_SYNC();
-
-            // ---- chroma prediction (h264_intra_prediction.c:2157-2564 + transform4x4_chroma): lane j < 8 predicts its own
-            //      4x4 block (plane j >> 2, block j & 3) ----
-            if (j < 8) {
-                const int pl = j >> 2, k = j & 3;
-                const int cx = (k & 1) * 4, cy = (k >> 1) * 4;
-                uint8_t *TCp = Tl.TC[pl];
-                const int4 ca = *reinterpret_cast<const int4 *>(&S.c2[j * 8]), cb = *reinterpret_cast<const int4 *>(&S.c2[j * 8 + 4]);
-                const int c2[8] = {ca.x, ca.y, ca.z, ca.w, cb.x, cb.y, cb.z, cb.w};
-                uint32_t pw[4] = {0u, 0u, 0u, 0u};
-                const uint32_t topw = *reinterpret_cast<const uint32_t *>(&TCp[8 + cx]);
-                const uint32_t lefw = *reinterpret_cast<const uint32_t *>(&R.LcolC[q][pl][cy]);
-                if (cmode == 0) {
-                    const int bx = k & 1, by = k >> 1;
-                    const int sH = sum4(topw), sV = sum4(lefw);
-                    int v;
-                    if (!A && !Bv) v = 128;
-                    else if (bx == by) {
-                        if (A && Bv) v = (sH + sV + 4) >> 3;
-                        else if (A) v = (sV + 2) >> 2;
-                        else v = (sH + 2) >> 2;
-                    } else if (bx == 1) { // xO > 0, yO == 0: prefers top
-                        v = Bv ? ((sH + 2) >> 2) : ((sV + 2) >> 2);
-                    } else {              // xO == 0, yO > 0: prefers left
-                        v = A ? ((sV + 2) >> 2) : ((sH + 2) >> 2);
-                    }
-                    pw[0] = pw[1] = pw[2] = pw[3] = (uint32_t)v * 0x01010101u;
-                } else if (cmode == 1) {
-                    if (A) {
-#pragma unroll
-                        for (int y = 0; y < 4; y++) pw[y] = ((lefw >> (8 * y)) & 255u) * 0x01010101u;
-                    }
-                } else if (cmode == 2) {
-                    if (Bv) pw[0] = pw[1] = pw[2] = pw[3] = topw;
-                } else if (cmode == 3) {
-                    if (A && Bv) {
-                        const uint2 topv = *reinterpret_cast<const uint2 *>(&TCp[8]);
-                        const uint2 lefv = *reinterpret_cast<const uint2 *>(R.LcolC[q][pl]);
-                        const int cor = TCp[7];
-                        const int Hh = plane_grad8(topv, (uint32_t)cor), Vv = plane_grad8(lefv, (uint32_t)cor);
-                        const int aa = 16 * ((int)(lefv.y >> 24) + (int)(topv.y >> 24));
-                        const int bb = (34 * Hh + 32) >> 6;
-                        const int cc = (34 * Vv + 32) >> 6;
-                        const int v00 = aa + bb * (cx - 3) + cc * (cy - 3) + 16;
-#pragma unroll
-                        for (int y = 0; y < 4; y++) pw[y] = plane_row(v00 + cc * y, bb);
-                    }
-                }
-                emit_block(&TCp[(cy + 1) * 16 + 8 + cx], 16, pw, c2);
-            }
+            PSTAMP(2);   // header, wait for the row above, top fetch
 
             // ---- luma prediction ----
             if (kind == MVHP_KIND_I16x16) {
@@ -689,45 +666,32 @@ __global__ __launch_bounds__(PIPE_ROWS * 3 * 64) void recon_pipe_kernel(ReconArg
                 }
             } else {
                 // I_PCM (8.3.5; only MVHP_STREAM_SPEC streams carry it): the samples as they are.  Record layout
-                // (minivideo_hotpath.h): the owner of luma block 2i holds luma rows 2i and 2i+1, the owner of block 2i+1 Cb row
-                // i and Cr row i.  (After the chroma prediction above, whose output these rows replace.)
-                WAVE_SYNC();
-                const int4 sA = *reinterpret_cast<const int4 *>(&S.res[j * 16]), sB = *reinterpret_cast<const int4 *>(&S.res[j * 16 + 8]);
-                const int jp = j >> 1;
+                // (minivideo_hotpath.h): the owner of luma block 2i holds luma rows 2i and 2i+1 (the owner of block 2i+1 Cb row
+                // i and Cr row i: O's part).
                 if ((j & 1) == 0) {
+                    const int4 sA = *reinterpret_cast<const int4 *>(&S.res[j * 16]), sB = *reinterpret_cast<const int4 *>(&S.res[j * 16 + 8]);
+                    const int jp = j >> 1;
                     *reinterpret_cast<int4 *>(&T[(2 * jp + 1) * 32 + 16]) = sA;
                     *reinterpret_cast<int4 *>(&T[(2 * jp + 2) * 32 + 16]) = sB;
-                } else {
-                    *reinterpret_cast<int2 *>(&Tl.TC[0][(jp + 1) * 16 + 8]) = make_int2(sA.x, sA.y);
-                    *reinterpret_cast<int2 *>(&Tl.TC[1][(jp + 1) * 16 + 8]) = make_int2(sA.z, sA.w);
                 }
             }
             WAVE_SYNC();
+            PSTAMP(4);   // luma (all paths some quarter takes)
 
-            // ---- neighbour state for the next macroblock (built in the OTHER tile) / the next row, then publish ----
+            // ---- luma neighbour state for the next macroblock (built in the OTHER tile) / the next row, then publish ----
             {
-                // corners (this macroblock's top-right samples) by lanes 0-2, left columns: lane j luma row j; lane j chroma
-                // row j & 7 of plane j >> 3; bottom rows -> line buffer by lanes 0-7 (one dword each)
+                // corner (this macroblock's top-right sample) by lane 0, left column: lane j row j; bottom row -> line buffer by
+                // lanes 0-3 (one dword each)
                 const uint8_t kl = T[(j + 1) * 32 + 31];
-                const uint8_t kc = Tl.TC[j >> 3][((j & 7) + 1) * 16 + 15];
-                uint8_t kk = 0;
-                uint8_t *kdst = &Tn.T[15];
-                if (j == 0) kk = T[31];
-                else if (j == 1) { kk = Tl.TC[0][15]; kdst = &Tn.TC[0][7]; }
-                else if (j == 2) { kk = Tl.TC[1][15]; kdst = &Tn.TC[1][7]; }
+                const uint8_t kk = T[31];
                 uint32_t bot = 0;
-                uint8_t *bdst = line_y;
-                if (j < 4) { bot = *reinterpret_cast<const uint32_t *>(&T[16 * 32 + 16 + j * 4]); bdst = &line_y[mbx * 16 + j * 4]; }
-                else if (j < 6) { bot = *reinterpret_cast<const uint32_t *>(&Tl.TC[0][8 * 16 + 8 + (j - 4) * 4]); bdst = &line_cb[mbx * 8 + (j - 4) * 4]; }
-                else if (j < 8) { bot = *reinterpret_cast<const uint32_t *>(&Tl.TC[1][8 * 16 + 8 + (j - 6) * 4]); bdst = &line_cr[mbx * 8 + (j - 6) * 4]; }
+                if (j < 4) bot = *reinterpret_cast<const uint32_t *>(&T[16 * 32 + 16 + j * 4]);
                 WAVE_SYNC();
                 Tn.T[(j + 1) * 32 + 15] = kl;
                 R.Lcol[q][j] = kl;
-                Tn.TC[j >> 3][((j & 7) + 1) * 16 + 7] = kc;
-                R.LcolC[q][j >> 3][j & 7] = kc;
-                if (j < 3) *kdst = kk;
-                if (j < 8) *reinterpret_cast<uint32_t *>(bdst) = bot;
-                if (seam_out && j < 8)   // the same eight dwords, tagged, to the band below (one write-through store per granule)
+                if (j == 0) Tn.T[15] = kk;
+                if (j < 4) *reinterpret_cast<uint32_t *>(&line_y[mbx * 16 + j * 4]) = bot;
+                if (seam_out && j < 4)   // the same four dwords, tagged, to the band below (one write-through store per granule)
                     __hip_atomic_store(seam_wr + qf * seam_pic + (uint32_t)(mbx * SEAM_GRANULES + j), ((unsigned long long)a.wide_epoch << 32) | bot,
                                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
@@ -736,18 +700,30 @@ __global__ __launch_bounds__(PIPE_ROWS * 3 * 64) void recon_pipe_kernel(ReconArg
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             if (lane == 0) __hip_atomic_store(&C.k_done[r], mbx + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             WAVE_SYNC();
+            PSTAMP(5);   // neighbour state, publish
         }
+#if defined(MVHP_PIPE_STAMPS)
+        if (lane_c == 0)
+            for (int i = 0; i < 8; i++) { atomicAdd(&g_pipe_stamps[i][0], ps_acc[i]); atomicAdd(&g_pipe_stamps[i][1], (unsigned long long)ps_n[i]); }
+#endif
         return;
     }
 
     // =============================================================================================================
-    // O: write-out (planar gather of export.c:65-188, mb_to_rgb export_utils.c:209-324 fused): park, or flush the
-    //    four-macroblock strip.  Strip owned by MACROBLOCK as in recon_quad.hip: lane (m, h) = (j & 3, j >> 2) of a quarter keeps
-    //    luma rows 4h .. 4h+3 of macroblock m of the strip and writes them when the strip is complete -- four adjacent lanes then
-    //    cover 64 contiguous bytes of a luma row (32 of a chroma row) per store instruction, and the 192 RGB bytes of a row leave
-    //    in three consecutive instructions.
+    // O: chroma prediction (h264_intra_prediction.c:2157-2564 + transform4x4_chroma) and write-out (planar gather of
+    //    export.c:65-188, mb_to_rgb export_utils.c:209-324 fused).  Chroma needs the macroblock above, not the one above-right:
+    //    this wave follows the row above's O by ONE macroblock.  Strip owned by MACROBLOCK as in recon_quad.hip: lane (m, h) =
+    //    (j & 3, j >> 2) of a quarter keeps luma rows 4h .. 4h+3 of macroblock m of the strip and writes them when the strip is
+    //    complete -- four adjacent lanes then cover 64 contiguous bytes of a luma row (32 of a chroma row) per store
+    //    instruction, and the 192 RGB bytes of a row leave in three consecutive instructions.
     // =============================================================================================================
     {
+        const bool seam_in = (r == 0) && band > 0;
+        const bool seam_out = (r == PIPE_ROWS - 1) && (row + 1 < H);
+        const uint32_t seam_pic = (uint32_t)((bands - 1) * W * SEAM_GRANULES);
+        const unsigned long long *seam_rd = seam_in ? a.seam + ((size_t)grp * 4 * (bands - 1) + (band - 1)) * W * SEAM_GRANULES : nullptr;
+        unsigned long long *seam_wr = seam_out ? a.seam + ((size_t)grp * 4 * (bands - 1) + band) * W * SEAM_GRANULES : nullptr;
+        unsigned long long seam_pend = 0;
         uint8_t *gyuv = a.yuv + (size_t)grp * 4 * W * H * 384;
         uint8_t *grgb = a.rgb + (size_t)grp * 4 * W * H * 768;
         v4i L0 = {0, 0, 0, 0}, L1 = L0, L2 = L0, L3 = L0;
@@ -756,8 +732,119 @@ __global__ __launch_bounds__(PIPE_ROWS * 3 * 64) void recon_pipe_kernel(ReconArg
             int lane = lane_c;
             asm volatile("" : "+v"(lane));
             const int q = lane >> 4, j = lane & 15;
-            const PTile &Tl = R.tile[mbx & 1][q];
+            const PSlot &S = R.slot[mbx % NSLOT][q];
+            const PTile &Tl = R.tile[mbx % NTILE][q];
+            uint8_t (*TC)[9 * 16] = R.TC[q];
             uint8_t (*SC)[8 * 24] = R.SC[q];
+            uint8_t *line_cb = lines + (size_t)q * W * 32 + W * 16;
+            uint8_t *line_cr = line_cb + W * 8;
+            const bool A = mbx > 0;
+
+            if (seam_in && (mbx & 1) == 0) {
+                // Macroblocks mbx and mbx + 1 read chroma columns mbx and mbx + 1 of the row above.  The first step of a row fetches
+                // (0, 1) now; every later even step finds its two columns asked for two steps ago, and asks for (mbx + 2, mbx + 3).
+                // Lane j < 8 of a quarter: column mbx + (j >> 2), granule 4 + (j & 3) (4-5 Cb dwords, 6-7 Cr).
+                const int g = 4 + (j & 3);
+                const uint32_t lo = qf * seam_pic + (uint32_t)g;
+                const int col = mbx + ((j >> 2) & 1);
+                const bool act = (j < 8) && (col < W);
+                const unsigned long long *src = seam_rd + lo + (uint32_t)((act ? col : 0) * SEAM_GRANULES);
+                unsigned long long v = seam_pend;
+                if (mbx == 0) v = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                int spins = 0;
+                while (__builtin_amdgcn_ballot_w64(act && (uint32_t)(v >> 32) != a.wide_epoch) != 0) {
+                    __builtin_amdgcn_s_sleep(2);
+                    bool stop = ++spins > (1 << 20) || __hip_atomic_load(&C.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (!stop && (spins & 255) == 0) stop = __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+                    if (stop) {
+                        if (lane == 0) { __hip_atomic_store(&C.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); atomicOr(a.err, 1u); }
+                        return;
+                    }
+                    v = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                if (act) {
+                    uint8_t *dst = (g < 6) ? &line_cb[col * 8 + (g - 4) * 4] : &line_cr[col * 8 + (g - 6) * 4];
+                    *reinterpret_cast<uint32_t *>(dst) = (uint32_t)v;
+                }
+                const int ncol = mbx + 2 + ((j >> 2) & 1);
+                if (j < 8 && ncol < W) seam_pend = __hip_atomic_load(seam_rd + lo + (uint32_t)(ncol * SEAM_GRANULES), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                WAVE_SYNC();
+            }
+
+            // header and chroma residuals of this macroblock; the row above's chroma of this column
+            if (!pipe_wait(&C.f_done[r], mbx + 1, C, a.err, lane)) return;
+            const uint32_t h0 = S.hdr[0];
+            const int kind = h0 & 255;
+            const int cmode = (h0 >> 24) & 255;
+            if (Bv) {
+                if (!seam_in && !pipe_wait(&C.c_done[r - 1], mbx + 1, C, a.err, lane)) return;
+                if (j < 4) {   // lanes 0-1 Cb top, 2-3 Cr top: one dword each
+                    const uint8_t *src = (j < 2) ? &line_cb[mbx * 8 + j * 4] : &line_cr[mbx * 8 + (j - 2) * 4];
+                    *reinterpret_cast<uint32_t *>(&TC[j >> 1][8 + (j & 1) * 4]) = *reinterpret_cast<const uint32_t *>(src);
+                }
+            }
+            WAVE_SYNC();
+
+            // ---- chroma prediction (h264_intra_prediction.c:2157-2564 + transform4x4_chroma): lane j < 8 predicts its own
+            //      4x4 block (plane j >> 2, block j & 3) ----
+            if (j < 8) {
+                const int pl = j >> 2, k = j & 3;
+                const int cx = (k & 1) * 4, cy = (k >> 1) * 4;
+                uint8_t *TCp = TC[pl];
+                const int4 ca = *reinterpret_cast<const int4 *>(&S.c2[j * 8]), cb = *reinterpret_cast<const int4 *>(&S.c2[j * 8 + 4]);
+                const int c2[8] = {ca.x, ca.y, ca.z, ca.w, cb.x, cb.y, cb.z, cb.w};
+                uint32_t pw[4] = {0u, 0u, 0u, 0u};
+                const uint32_t topw = *reinterpret_cast<const uint32_t *>(&TCp[8 + cx]);
+                const uint32_t lefw = *reinterpret_cast<const uint32_t *>(&R.LcolC[q][pl][cy]);
+                if (cmode == 0) {
+                    const int bx = k & 1, by = k >> 1;
+                    const int sH = sum4(topw), sV = sum4(lefw);
+                    int v;
+                    if (!A && !Bv) v = 128;
+                    else if (bx == by) {
+                        if (A && Bv) v = (sH + sV + 4) >> 3;
+                        else if (A) v = (sV + 2) >> 2;
+                        else v = (sH + 2) >> 2;
+                    } else if (bx == 1) { // xO > 0, yO == 0: prefers top
+                        v = Bv ? ((sH + 2) >> 2) : ((sV + 2) >> 2);
+                    } else {              // xO == 0, yO > 0: prefers left
+                        v = A ? ((sV + 2) >> 2) : ((sH + 2) >> 2);
+                    }
+                    pw[0] = pw[1] = pw[2] = pw[3] = (uint32_t)v * 0x01010101u;
+                } else if (cmode == 1) {
+                    if (A) {
+#pragma unroll
+                        for (int y = 0; y < 4; y++) pw[y] = ((lefw >> (8 * y)) & 255u) * 0x01010101u;
+                    }
+                } else if (cmode == 2) {
+                    if (Bv) pw[0] = pw[1] = pw[2] = pw[3] = topw;
+                } else if (cmode == 3) {
+                    if (A && Bv) {
+                        const uint2 topv = *reinterpret_cast<const uint2 *>(&TCp[8]);
+                        const uint2 lefv = *reinterpret_cast<const uint2 *>(R.LcolC[q][pl]);
+                        const int cor = TCp[7];
+                        const int Hh = plane_grad8(topv, (uint32_t)cor), Vv = plane_grad8(lefv, (uint32_t)cor);
+                        const int aa = 16 * ((int)(lefv.y >> 24) + (int)(topv.y >> 24));
+                        const int bb = (34 * Hh + 32) >> 6;
+                        const int cc = (34 * Vv + 32) >> 6;
+                        const int v00 = aa + bb * (cx - 3) + cc * (cy - 3) + 16;
+#pragma unroll
+                        for (int y = 0; y < 4; y++) pw[y] = plane_row(v00 + cc * y, bb);
+                    }
+                }
+                emit_block(&TCp[(cy + 1) * 16 + 8 + cx], 16, pw, c2);
+            }
+
+            if (kind == MVHP_KIND_IPCM && (j & 1)) {
+                // I_PCM (see K): the owner of luma block 2i + 1 holds Cb row i and Cr row i, over what the prediction made
+                const int4 sA = *reinterpret_cast<const int4 *>(&S.res[j * 16]);
+                const int jp = j >> 1;
+                *reinterpret_cast<int2 *>(&TC[0][(jp + 1) * 16 + 8]) = make_int2(sA.x, sA.y);
+                *reinterpret_cast<int2 *>(&TC[1][(jp + 1) * 16 + 8]) = make_int2(sA.z, sA.w);
+            }
+            WAVE_SYNC();
+
+            // ---- the luma of this macroblock: park, or flush the strip ----
             if (!pipe_wait(&C.k_done[r], mbx + 1, C, a.err, lane)) return;
             const int mbi = mbx & 3;
             const int m_own = j & 3, h_own = j >> 2;
@@ -771,19 +858,43 @@ __global__ __launch_bounds__(PIPE_ROWS * 3 * 64) void recon_pipe_kernel(ReconArg
             if (flush) {
                 // chroma rows 2h, 2h + 1 of the lane's macroblock: parked ones from the strip, the current one from the tile
                 const bool cur = (m_own == mbi);
-                const uint8_t *cb_src = cur ? &Tl.TC[0][(2 * h_own + 1) * 16 + 8] : &SC[0][2 * h_own * 24 + m_own * 8];
-                const uint8_t *cr_src = cur ? &Tl.TC[1][(2 * h_own + 1) * 16 + 8] : &SC[1][2 * h_own * 24 + m_own * 8];
+                const uint8_t *cb_src = cur ? &TC[0][(2 * h_own + 1) * 16 + 8] : &SC[0][2 * h_own * 24 + m_own * 8];
+                const uint8_t *cr_src = cur ? &TC[1][(2 * h_own + 1) * 16 + 8] : &SC[1][2 * h_own * 24 + m_own * 8];
                 const int cstep = cur ? 16 : 24;
                 cb0 = *reinterpret_cast<const uint2 *>(cb_src); cb1 = *reinterpret_cast<const uint2 *>(cb_src + cstep);
                 cr0 = *reinterpret_cast<const uint2 *>(cr_src); cr1 = *reinterpret_cast<const uint2 *>(cr_src + cstep);
             } else {
                 // park the chroma rows (lane j: row j & 7 of plane j >> 3) in the LDS strip
-                const uint2 cv = *reinterpret_cast<const uint2 *>(&Tl.TC[j >> 3][((j & 7) + 1) * 16 + 8]);
+                const uint2 cv = *reinterpret_cast<const uint2 *>(&TC[j >> 3][((j & 7) + 1) * 16 + 8]);
                 *reinterpret_cast<uint2 *>(&SC[j >> 3][(j & 7) * 24 + mbi * 8]) = cv;
             }
-            // the tile has been read: K may build macroblock mbx + 2 in it
+            // the luma tile and the ring slot have been read: K may build macroblock mbx + 2 in the tile, F may refill the slot
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             if (lane == 0) __hip_atomic_store(&C.o_done[r], mbx + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+
+            // ---- chroma neighbour state for the next macroblock / the next row, then publish the chroma ----
+            {
+                // corners (this macroblock's top-right samples) by lanes 0-1, left columns: lane j row j & 7 of plane j >> 3;
+                // bottom rows -> line buffer by lanes 0-3 (one dword each)
+                const uint8_t kc = TC[j >> 3][((j & 7) + 1) * 16 + 15];
+                uint8_t kk = 0;
+                if (j < 2) kk = TC[j][15];
+                uint32_t bot = 0;
+                uint8_t *bdst = line_cb;
+                if (j < 2) { bot = *reinterpret_cast<const uint32_t *>(&TC[0][8 * 16 + 8 + j * 4]); bdst = &line_cb[mbx * 8 + j * 4]; }
+                else if (j < 4) { bot = *reinterpret_cast<const uint32_t *>(&TC[1][8 * 16 + 8 + (j - 2) * 4]); bdst = &line_cr[mbx * 8 + (j - 2) * 4]; }
+                WAVE_SYNC();
+                TC[j >> 3][((j & 7) + 1) * 16 + 7] = kc;
+                R.LcolC[q][j >> 3][j & 7] = kc;
+                if (j < 2) TC[j][7] = kk;
+                if (j < 4) *reinterpret_cast<uint32_t *>(bdst) = bot;
+                if (seam_out && j < 4)   // the same four dwords, tagged, to the band below (granules 4-7 of the column)
+                    __hip_atomic_store(seam_wr + qf * seam_pic + (uint32_t)(mbx * SEAM_GRANULES + 4 + j), ((unsigned long long)a.wide_epoch << 32) | bot,
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (lane == 0) __hip_atomic_store(&C.c_done[r], mbx + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+
             if (flush && m_own <= mbi && valid) {
                 const uint32_t x0 = (uint32_t)((mbx & ~3) * 16 + m_own * 16);
                 const uint32_t lrow = (uint32_t)((row * 16 + 4 * h_own) * pitch) + x0;     // luma row 4h of the macroblock row
@@ -849,3 +960,15 @@ hipError_t launch_recon_pipe(const ReconArgs &a, int rows, hipStream_t stream)
 }
 
 } // namespace mvhp
+
+#if defined(MVHP_PIPE_STAMPS)
+extern "C" __attribute__((visibility("default"))) int mvhp_debug_pipe_stamps(unsigned long long *out, int clear)
+{
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(mvhp::g_pipe_stamps), sizeof(mvhp::g_pipe_stamps)) != hipSuccess) return 0;
+    if (clear) {
+        static const unsigned long long zero[16][2] = {};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(mvhp::g_pipe_stamps), zero, sizeof(zero)) != hipSuccess) return 0;
+    }
+    return 1;
+}
+#endif
