@@ -308,7 +308,7 @@ static int pick_waves(const mvhp_ctx *c, const mvhp_stream_params_t *p, int n_fr
     // speed only (DESIGN.md "waves per picture"): 8-wave workgroups fit three to a CU (LDS) = 24 waves/CU,
     // 16-wave workgroups one to a CU; small batches need the wider workgroup to occupy the chip.
     if (nw == 0) nw = (n_frames >= 384) ? 8 : 16;
-    if (nw == 6) nw = 4;
+    if (nw < 4 || nw == 6) nw = 4;   // (1 and 2 are rows per band of the pipe form)
     if (nw == 12) nw = 8;
     while (nw > 4 && (nw / 2) >= (int)p->height_mbs) nw /= 2;
     while (nw > 4 && mvhp::recon_lds_bytes((int)p->width_mbs, nw) > c->max_lds) nw /= 2;

@@ -137,7 +137,7 @@ class HotPath:
 
     def set_waves_per_picture(self, waves):
         if self._L.mvhp_set_waves_per_picture(self._h, int(waves)) != SUCCESS:
-            raise MiniVideoError("waves per picture must be 0 (auto), 4, 8 or 16")
+            raise MiniVideoError("waves per picture must be 0 (auto), 1, 2, 4, 6, 8, 12 or 16")
 
     def set_layout(self, layout):
         """0 auto, 1 one picture per workgroup (rows), 2 four pictures per workgroup (quad), 3 eight (oct), 4 one picture over

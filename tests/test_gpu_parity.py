@@ -36,7 +36,7 @@ def test_dense_small(hot, W, H, profile):
     _check(hot, params, rec, 3)
 
 
-@pytest.mark.parametrize("waves", [4, 8, 16])
+@pytest.mark.parametrize("waves", [1, 2, 4, 8, 16])   # (1, 2: rows per band of the pipe form; the others take the next size they are built for)
 def test_waves_per_picture(hot, waves):
     hot.set_waves_per_picture(waves)
     try:
