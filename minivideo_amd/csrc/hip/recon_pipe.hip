@@ -1,7 +1,7 @@
 // recon_pipe.hip -- the low-latency form of the reconstruction kernel (gfx950 only): a macroblock row is worked on by THREE
 // wavefronts in a pipeline, and a picture's rows are spread over several workgroups.
 //
-//   recon_pipe_kernel<RGB>  same contract as recon_quad_kernel (recon_quad.hip): replaces intra_prediction_process()
+//   recon_pipe_kernel<R, RGB>  same contract as recon_quad_kernel (recon_quad.hip): replaces intra_prediction_process()
 //                           (decoder/h264/h264_intra_prediction.c:112-145), all of h264_transform.c, the planar gather of
 //                           export.c:65-188 and mb_to_rgb() (export_utils.c:209-324) for whole pictures.
 //
@@ -11,16 +11,17 @@
 // dependent prediction chain, colour conversion and stores one after the other.  Only the prediction depends on the
 // neighbours.  Here a row has
 //   F  the residual wave: reads the packed records (the only wave that loads from HBM), dequantises, inverse-transforms and
-//      leaves header + residuals of macroblock x in slot x % 2 of a ring in LDS -- no dependency on anything but a free slot;
-//   K  the luma wave: waits for the row above (or the seam), predicts luma into tile x % 2, adds the residuals, hands the
+//      leaves header + residuals of macroblock x in slot x % 4 of a ring in LDS -- no dependency on anything but a free slot;
+//   K  the luma wave: waits for the row above (or the seam), predicts luma into tile x % 3, adds the residuals, hands the
 //      bottom row / right column on, publishes -- the chain every other row waits for, and nothing else;
 //   O  the chroma + output wave: chroma prediction is independent of luma and needs no up-right neighbour, so it runs here,
 //      one macroblock behind the row above's O; then the finished macroblock is parked in the four-macroblock strip,
 //      converted to RGB and stored (the only wave that writes HBM).
-// The three run on one SIMD (waves w, w + 4, w + 8 of the workgroup), so K's LDS round trips are filled with F's and O's
+// The three run on one SIMD (waves w, w + R, w + 2R of the workgroup), so K's LDS round trips are filled with F's and O's
 // arithmetic.  Four pictures per wavefront, 16 lanes each, exactly as recon_quad.hip (lane j owns luma 4x4 block j and, for
-// j < 8, chroma block j); a workgroup = one band of four rows = 12 wavefronts; bands, tickets and seams as
-// recon_quad_kernel<.., WIDE> (the seam format is the same).
+// j < 8, chroma block j); a workgroup = one band of R = 1, 2 or 4 rows = 3 R wavefronts; bands, tickets and seams as
+// recon_quad_kernel<.., WIDE> (the seam format is the same; a column's granules 0-3 are K's, 4-7 are O's).
+// Measured (profiles/r04f_*): 64 x 1080p Baseline 0.97 ms (recon_rows_kernel in bands: 1.28), 16 pictures 0.78, one picture 0.58.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
