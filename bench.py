@@ -108,14 +108,14 @@ def measured_traffic(args, fused, kernel, frames):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes of THIS command
     (tools/profile_config.sh: FETCH_SIZE and WRITE_SIZE in separate passes; FETCH_SIZE doubled per the gfx950
     correction in MI355X_MICROARCH.md).  Only reported when the run uses a profiled configuration."""
-    if not (args.density == "dense" and args.source == "stream" and fused and not args.waves and args.layout == "auto"
-            and not args.strong):
+    if not (args.density == "dense" and args.source == "stream" and fused and not args.waves and args.layout == "auto"):
         return None, None
     tag = {("baseline", 120, 68, 2048): "base1080", ("high", 120, 68, 2048): "high1080",
-           ("high", 240, 135, 1024): "high2160"}.get((args.profile, args.width_mbs, args.height_mbs, frames))
+           ("high", 240, 135, 1024): "high2160", ("baseline", 120, 68, 512): "strong512",
+           ("baseline", 120, 68, 64): "frames64"}.get((args.profile, args.width_mbs, args.height_mbs, frames))
     if tag is None:
         return None, None
-    for rnd in ("r03b", "r03a", "r02f", "r02e", "r02d", "r02c", "r02b", "r02a"):
+    for rnd in ("r04h", "r04c", "r03b", "r03a", "r02f", "r02e", "r02d", "r02c", "r02b", "r02a"):
         name = f"{rnd}_{tag}_pmc_summary.json"
         path = os.path.join(ROOT, "profiles", name)
         if os.path.exists(path):
