@@ -125,6 +125,18 @@ def measured_traffic(args, fused, kernel, frames):
     return None, None
 
 
+def other_frac(placement, algorithmic_bytes):
+    """roofline fraction of the launch timed on the other kind of buffers (`placement`), or None"""
+    if not placement:
+        return None
+    key = "ms_per_step_on_placed_buffers" if "ms_per_step_on_placed_buffers" in placement else "ms_per_step_on_ordinary_allocations"
+    ms = [v for v in placement.get(key, []) if v]
+    if not ms:
+        return None
+    return {"buffers": "mvhp_placed_alloc" if "placed" in key else "ordinary allocations",
+            "ms_per_step": ms, "frac": [round(algorithmic_bytes / (v * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) for v in ms]}
+
+
 def host_cores():
     """Cores this process may use: hardware threads cut down to the container's CPU quota (cgroup cpu.max)."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -813,6 +825,9 @@ def main():
                 "traffic_source": traffic_src,
                 "algorithmic_gb_per_launch": mbs_per_step * (bpm if dom_recon else BYTES_PER_MB_COLOR) / 1e9,
                 "bytes_per_macroblock": bpm if dom_recon else BYTES_PER_MB_COLOR,
+                # the same launch on the other kind of buffers (placement: where a batch's buffers lie in device memory is
+                # worth up to 25 % of a launch on some boxes, nothing on others -- DESIGN.md 7); never part of `frac`
+                "frac_on_the_other_buffers": other_frac(placement, mbs_per_step * (bpm if dom_recon else BYTES_PER_MB_COLOR)),
             },
             "end_to_end": e2e,
             "engine_multi_context": multi,
