@@ -57,7 +57,7 @@ def parse_args():
                     help="with --source records: P(Intra16x16), P(Intra8x8 | not Intra16x16) instead of the profile's mix "
                          "(content ablations: which macroblock kinds cost what; never a BASELINE.json configuration)")
     ap.add_argument("--waves", type=int, default=0)
-    ap.add_argument("--layout", default="auto", choices=["auto", "rows", "quad", "oct", "wide", "quad_wide", "pipe"],
+    ap.add_argument("--layout", default="auto", choices=["auto", "rows", "quad", "oct", "wide", "quad_wide", "pipe", "pipe1"],
                     help="pictures per workgroup: rows = 1 (one wavefront per macroblock row), quad = 4, oct = 8; "
                          "wide / quad_wide = one picture / four pictures over several workgroups")
     ap.add_argument("--no-rgb", action="store_true")
@@ -332,7 +332,7 @@ def end_to_end(args, params, stream, n_distinct, rec, want_rgb, total, rank, wor
         "h2d": {"busy_s": st["h2d_s"], "share_of_wall": st["h2d_s"] / w, "GB/s": st["h2d_bytes"] / max(st["h2d_s"], 1e-9) / 1e9},
         "kernels": {"busy_s": st["kernel_s"], "share_of_wall": st["kernel_s"] / w, "launches": st["batches"],
                     "largest_batch": st["max_batch_pictures"],
-                    "by_layout": dict(zip(["auto", "rows", "quad", "oct", "wide", "quad_wide", "pipe"], list(st["launches_by_layout"]) + list(st["launches_wide"])))},
+                    "by_layout": dict(zip(["auto", "rows", "quad", "oct", "wide", "quad_wide", "pipe", "pipe1"], list(st["launches_by_layout"]) + list(st["launches_wide"])))},
         "d2h": {"busy_s": st["d2h_s"], "share_of_wall": st["d2h_s"] / w, "GB/s": st["d2h_bytes"] / max(st["d2h_s"], 1e-9) / 1e9},
     }
     bound = max(stages, key=lambda k: stages[k]["share_of_wall"])
@@ -414,7 +414,7 @@ def engine_multi_context(args, params, stream, n_distinct, rec, want_rgb, n_ctx,
         "rehearsal_contexts_share_devices": n_ctx > n_devices,
         "value": pictures * params.mbs / wall, "unit": "macroblocks/s", "pictures": pictures, "wall_s": wall,
         "contexts": st["contexts"], "launches": st["batches"], "largest_batch": st["max_batch_pictures"],
-        "by_layout": dict(zip(["auto", "rows", "quad", "oct", "wide", "quad_wide", "pipe"], list(st["launches_by_layout"]) + list(st["launches_wide"]))),
+        "by_layout": dict(zip(["auto", "rows", "quad", "oct", "wide", "quad_wide", "pipe", "pipe1"], list(st["launches_by_layout"]) + list(st["launches_wide"]))),
         "entropy_share_of_wall": st["entropy_busy_s"] / max(1, st["host_threads"]) / st["wall_s"],
         "bit_exact_vs_oracle": ok,
     }
@@ -665,7 +665,7 @@ def main():
     hot.sync_check(sp)
     layout_name, waves_used = hot.last_launch()   # what the library chose (speed only)
     recon_name = {"rows": "recon_rows_kernel", "quad": "recon_quad_kernel", "oct": "recon_oct_kernel",
-                  "wide": "recon_rows_kernel", "quad_wide": "recon_quad_kernel", "pipe": "recon_pipe_kernel"}[layout_name]
+                  "wide": "recon_rows_kernel", "quad_wide": "recon_quad_kernel", "pipe": "recon_pipe_kernel", "pipe1": "recon_pipe1_kernel"}[layout_name]
 
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else dev)
@@ -803,7 +803,9 @@ def main():
                                  "quad_wide": "four pictures (16 lanes each) over several workgroups (bands of macroblock rows, "
                                               "seams through global memory)",
                                  "pipe": "four pictures (16 lanes each) over several workgroups (bands of four macroblock rows, seams "
-                                         "through global memory), three wavefronts per row: residuals / prediction / write-out"}[layout_name]
+                                         "through global memory), three wavefronts per row: residuals / luma / chroma + write-out",
+                                 "pipe1": "one picture over several workgroups (bands of four macroblock rows, seams through global memory), "
+                                          "three wavefronts per row: residuals / luma / chroma + write-out"}[layout_name]
                                 + f", {waves_used} wavefronts per workgroup, pictures sharded over {world} GPU(s), no collectives"),
                 "bit_exact_vs_oracle": ok,
             },

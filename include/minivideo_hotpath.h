@@ -262,7 +262,10 @@ MVHP_EXPORT int  mvhp_set_waves_per_picture(mvhp_ctx_t *ctx, int waves);
 /* MVHP_LAYOUT_PIPE: four pictures over several workgroups as QUAD_WIDE, and every macroblock row worked on by THREE wavefronts
  * in a pipeline (residuals / prediction / write-out): the shortest macroblock step, i.e. the lowest latency of a small batch. */
 #define MVHP_LAYOUT_PIPE      6
-#define MVHP_LAYOUT_COUNT     7
+/* MVHP_LAYOUT_PIPE1: the same pipeline with ONE picture per wavefront (nothing runs in lock step with another picture): the
+ * lowest latency of a handful of pictures on any profile; also reconstructs slices / scaling matrices. */
+#define MVHP_LAYOUT_PIPE1     7
+#define MVHP_LAYOUT_COUNT     8
 MVHP_EXPORT int  mvhp_set_layout(mvhp_ctx_t *ctx, int layout);
 
 /* ---------------------------------------------------------------------------
@@ -312,8 +315,7 @@ typedef struct mvhp_decode_stats {
     uint64_t host_alloc_bytes, dev_alloc_bytes;
     uint32_t placed_buffers;       /* 1: the device batch buffers come from mvhp_placed_alloc (MINIVIDEO_PLACED=1)   */
     uint32_t reserved;
-    uint32_t launches_wide[3];     /* launches on MVHP_LAYOUT_WIDE, _QUAD_WIDE, _PIPE (launches_by_layout covers 0..3)      */
-    uint32_t reserved2;
+    uint32_t launches_wide[4];     /* launches on MVHP_LAYOUT_WIDE, _QUAD_WIDE, _PIPE, _PIPE1 (launches_by_layout: 0..3)   */
 } mvhp_decode_stats_t;
 
 /* Called on the calling thread, once per picture, in the order of `order`.  rc = MVHP_SUCCESS: yuv (and rgb when

@@ -128,6 +128,7 @@ MVHP_EXPORT int mvhp_create(int device, mvhp_ctx_t **out)
         else if (!strcmp(e, "wide")) c->layout = MVHP_LAYOUT_WIDE;
         else if (!strcmp(e, "quad_wide")) c->layout = MVHP_LAYOUT_QUAD_WIDE;
         else if (!strcmp(e, "pipe")) c->layout = MVHP_LAYOUT_PIPE;
+        else if (!strcmp(e, "pipe1")) c->layout = MVHP_LAYOUT_PIPE1;
     }
     c->n_cus = prop.multiProcessorCount;
     c->max_lds = prop.maxSharedMemoryPerMultiProcessor ? prop.maxSharedMemoryPerMultiProcessor : 65536;
@@ -211,13 +212,23 @@ MVHP_EXPORT int mvhp_set_fused_color(mvhp_ctx_t *c, int on)
 //   128 / 256 / 512 pictures, pipe 1.18 / 1.45 / 1.82, quad_wide 1.91 / 2.05 / 2.39 / 2.84 / 3.95 -- the four pictures of a
 //   wavefront run their three luma paths one after the other -- so there: wide up to 1.3 x CUs pictures, then quad_wide.
 //   Up to three pictures the quarters of a wavefront hold the SAME picture (no divergence): pipe on every profile (0.58 / 0.67 ms).
+//   pipe1 = the same three waves per row with ONE picture per wavefront (no lock step at all; profiles/r04i_crossover_*.log):
+//   Baseline 0.72 / 0.72 / 1.02 / 1.61 / 2.91 ms at 1 / 16 / 64 / 128 / 256 pictures (within 8 % of pipe up to 32 pictures, behind
+//   it beyond), High 0.64 / 0.70 / 0.98 / 1.58 / 2.88 -- against wide's 1.07 / 1.35 / 1.70 / 2.58 at 16 / 64 / 128 / 256: High
+//   batches up to 0.6 x CUs pictures of 68 rows (40 x CUs row-waves) take pipe1, and so do small batches with slices / scaling
+//   matrices, which it reconstructs as the one-picture kernel does.
 static int pick_layout(const mvhp_ctx *c, const mvhp_stream_params_t *p, int n_frames)
 {
     int layout = c->layout;
     // pictures of several slices and scaling matrices (MVHP_STREAM_SPEC streams): the one-picture kernel,
     // where a neighbour's availability is a per-wavefront scalar and LevelScale is a table in LDS -- whatever was asked for;
     // in bands at every batch size (2.44 against 2.58 ms at 256 pictures, 8.5 against 8.9 at 1024) unless "rows" is forced
-    if (p->flags & (MVHP_PARAM_SLICES | MVHP_PARAM_SCALING)) return (layout == MVHP_LAYOUT_ROWS) ? MVHP_LAYOUT_ROWS : MVHP_LAYOUT_WIDE;
+    const bool pipe1_fits = mvhp::recon_pipe1_lds_bytes((int)p->width_mbs, 1) <= c->max_lds;
+    if (p->flags & (MVHP_PARAM_SLICES | MVHP_PARAM_SCALING)) {
+        if (layout == MVHP_LAYOUT_ROWS || layout == MVHP_LAYOUT_WIDE) return layout;
+        if (layout == MVHP_LAYOUT_PIPE1) return pipe1_fits ? MVHP_LAYOUT_PIPE1 : MVHP_LAYOUT_WIDE;
+        return (pipe1_fits && (double)n_frames * (double)p->height_mbs <= 40.0 * c->n_cus) ? MVHP_LAYOUT_PIPE1 : MVHP_LAYOUT_WIDE;
+    }
     if (layout == MVHP_LAYOUT_AUTO) {
         const double cus = (double)c->n_cus;
         const double row_waves = (double)n_frames * (double)p->height_mbs;
@@ -225,6 +236,8 @@ static int pick_layout(const mvhp_ctx *c, const mvhp_stream_params_t *p, int n_f
         const bool pipe_fits = mvhp::recon_pipe_lds_bytes((int)p->width_mbs, 1) <= c->max_lds;
         if (pipe_fits && (n_frames <= 3 || (!may8 && row_waves <= 68.0 * cus))) {
             layout = MVHP_LAYOUT_PIPE;
+        } else if (pipe1_fits && may8 && row_waves <= 40.0 * cus) {
+            layout = MVHP_LAYOUT_PIPE1;
         } else if (row_waves <= (may8 ? 90.0 : 34.0) * cus) {
             layout = MVHP_LAYOUT_WIDE;
         } else if (row_waves <= 238.0 * cus) {
@@ -249,6 +262,7 @@ static int pick_layout(const mvhp_ctx *c, const mvhp_stream_params_t *p, int n_f
     if (layout == MVHP_LAYOUT_OCT && (mbs > ((size_t)1 << 19) || mvhp::recon_oct_lds_bytes((int)p->width_mbs, 4) > c->max_lds))
         layout = MVHP_LAYOUT_QUAD;
     if (layout == MVHP_LAYOUT_QUAD && mvhp::recon_quad_lds_bytes((int)p->width_mbs, 4) > c->max_lds) layout = MVHP_LAYOUT_ROWS;
+    if (layout == MVHP_LAYOUT_PIPE1 && mvhp::recon_pipe1_lds_bytes((int)p->width_mbs, 1) > c->max_lds) layout = MVHP_LAYOUT_WIDE;
     if (layout == MVHP_LAYOUT_PIPE && (mbs > ((size_t)1 << 20) || mvhp::recon_pipe_lds_bytes((int)p->width_mbs, 1) > c->max_lds))
         layout = MVHP_LAYOUT_QUAD_WIDE;
     if (layout == MVHP_LAYOUT_QUAD_WIDE && (mbs > ((size_t)1 << 20) || mvhp::recon_quad_lds_bytes((int)p->width_mbs, 4) > c->max_lds))
@@ -259,11 +273,12 @@ static int pick_layout(const mvhp_ctx *c, const mvhp_stream_params_t *p, int n_f
 static int pick_waves(const mvhp_ctx *c, const mvhp_stream_params_t *p, int n_frames, int layout)
 {
     int nw = c->waves;
-    if (layout == MVHP_LAYOUT_PIPE) {
+    if (layout == MVHP_LAYOUT_PIPE || layout == MVHP_LAYOUT_PIPE1) {
         // rows per band (three wavefronts each), built for 1, 2 and 4
         if (nw == 0) nw = 4;
         nw = (nw >= 4) ? 4 : (nw >= 2 ? 2 : 1);
-        while (nw > 1 && mvhp::recon_pipe_lds_bytes((int)p->width_mbs, nw) > c->max_lds) nw /= 2;
+        while (nw > 1 && (layout == MVHP_LAYOUT_PIPE ? mvhp::recon_pipe_lds_bytes((int)p->width_mbs, nw)
+                                                      : mvhp::recon_pipe1_lds_bytes((int)p->width_mbs, nw)) > c->max_lds) nw /= 2;
         return nw;
     }
     if (layout == MVHP_LAYOUT_WIDE) return 4;   // rows per band (built for 4: the finest grain, 17 bands per 1080p picture)
@@ -392,6 +407,12 @@ static int launch_all(mvhp_ctx *c, const mvhp_stream_params_t *p, const void *d_
             if (rc != MVHP_SUCCESS) return rc;
             HIP_TRY(mvhp::launch_recon_pipe(a, nw, st));
             c->ticket_base += (uint32_t)((n_frames + 3) / 4) * (uint32_t)((a.height_mbs + nw - 1) / nw);
+            HIP_TRY(hipEventRecord(c->wide_done, st));
+        } else if (layout == MVHP_LAYOUT_PIPE1) {
+            const int rc = wide_prepare(c, a, mvhp::recon_wide_seam_bytes(a.width_mbs, a.height_mbs, n_frames, nw), 0, st);
+            if (rc != MVHP_SUCCESS) return rc;
+            HIP_TRY(mvhp::launch_recon_pipe1(a, nw, st));
+            c->ticket_base += (uint32_t)n_frames * (uint32_t)((a.height_mbs + nw - 1) / nw);
             HIP_TRY(hipEventRecord(c->wide_done, st));
         } else if (layout == MVHP_LAYOUT_QUAD_WIDE) {
             const int rc = wide_prepare(c, a, mvhp::recon_wide_seam_bytes(a.width_mbs, a.height_mbs, n_frames, nw), 0, st);

@@ -65,6 +65,9 @@ hipError_t launch_recon_quad_wide(const ReconArgs &a, int nw, hipStream_t stream
 // four pictures per wavefront in bands of four rows, three wavefronts per row (recon_pipe.hip); seams as the wide form with nw = 4
 size_t     recon_pipe_lds_bytes(int width_mbs, int rows);
 hipError_t launch_recon_pipe(const ReconArgs &a, int rows, hipStream_t stream);   // rows per band: 1, 2 or 4
+// the same pipeline with one picture per wavefront (recon_pipe1.hip); handles slices / scaling matrices
+size_t     recon_pipe1_lds_bytes(int width_mbs, int rows);
+hipError_t launch_recon_pipe1(const ReconArgs &a, int rows, hipStream_t stream);
 // eight pictures per workgroup, 8 lanes per picture (recon_oct.hip)
 size_t     recon_oct_lds_bytes(int width_mbs, int nw);
 hipError_t launch_recon_oct(const ReconArgs &a, int nw, hipStream_t stream);

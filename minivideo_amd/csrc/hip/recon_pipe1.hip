@@ -1,0 +1,972 @@
+// recon_pipe1.hip -- the low-latency form for ONE picture per wavefront (gfx950 only): a macroblock row is worked on by THREE
+// wavefronts in a pipeline, a picture's rows are spread over several workgroups, and nothing runs in lock step with another
+// picture.
+//
+//   recon_pipe1_kernel<R, EXT>  same contract as recon_rows_kernel (recon_kernels.hip): replaces intra_prediction_process()
+//                               (decoder/h264/h264_intra_prediction.c:112-145), all of h264_transform.c, the planar gather of
+//                               export.c:65-188 and mb_to_rgb() (export_utils.c:209-324) for whole pictures.
+//
+// recon_pipe_kernel (recon_pipe.hip) does this with four pictures per wavefront: its luma wave runs the Intra16x16 path, the
+// Intra4x4 chain and (High profile) the four Intra8x8 blocks one after the other whenever its four pictures disagree on the
+// macroblock kind, which they nearly always do.  Here a wavefront has ONE picture, so the luma wave's step is the path of that
+// macroblock alone, on 64 lanes (the arithmetic and the lane mappings are recon_rows_kernel's):
+//   F  records -> dequantised, inverse-transformed residuals of a macroblock PAIR + the two headers, in a ring in LDS;
+//   K  wait for the row above (or the luma granules of the seam), luma prediction + residual add into a ring of tiles, luma
+//      neighbour state, publish;
+//   O  chroma prediction (one macroblock behind the row above's O: no up-right dependency), 4-macroblock output strip, colour
+//      conversion, stores.
+// Bands of R = 1, 2 or 4 rows per workgroup (3 R wavefronts), band-major tickets and seam granules as the other wide forms
+// (granules 0-3 of a column are K's, 4-7 O's).  EXT: pictures of several slices and scaling matrices (MVHP_PARAM_SLICES /
+// MVHP_PARAM_SCALING), as recon_rows_kernel<.., EXT>.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "minivideo_hotpath.h"
+#include "recon_kernels.h"
+#include "recon_device.h"
+#include "recon_batch_device.h"
+
+namespace mvhp {
+namespace p1 {
+
+constexpr int ROWS_MAX = 4;
+constexpr int NPAIR = 3;    // F -> K / O ring, in macroblock PAIRS: F may be this many pairs ahead of the slower of K and O
+constexpr int NTILE = 3;    // K -> O ring of luma tiles
+
+struct __attribute__((aligned(16))) P1Tables {   // as BlockLds of recon_kernels.hip, without the counters
+    int     ls4[18];       // LevelScale4x4 classes, 16*normAdjust (h264.c:427-435)
+    int     ls8[36];       // LevelScale8x8 classes (h264.c:438-446)
+    int     pad[2];
+    uint8_t cls8[64];      // 8x8 position -> class
+    uint8_t w4[3][16];     // weight matrices (raster), 16 = flat: LevelScale = weight * normAdjust (h264_transform.c:645-741)
+    uint8_t w8[64];
+    uint32_t tap4[2 * 9 * 16]; // Intra4x4: [up-right unavailable][mode][sample] -> three byte offsets into the tile
+    uint32_t tap8[9 * 64];     // Intra8x8: [mode][sample] -> three indices into the filtered edge array E8
+};
+
+struct __attribute__((aligned(16))) P1Ctl {
+    int f_done[ROWS_MAX];      // macroblocks whose residuals + headers F has left in the ring (a multiple of 2, or W)
+    int k_done[ROWS_MAX];      // macroblocks whose luma K has finished
+    int o_done[ROWS_MAX];      // macroblocks O has taken out of their tile and ring slot
+    int c_done[ROWS_MAX];      // macroblocks whose chroma O has finished (what the row below's O waits for)
+    int abort_flag;
+    int unit;
+    int pad[2];
+};
+
+struct __attribute__((aligned(16))) P1Row {
+    int16_t  res[NPAIR][2][384];   // F -> K / O: residuals of a macroblock pair, MB raster: luma y*16+x | 256+Cb y*8+x | 320+Cr
+    uint32_t hdr[NPAIR][2][8];     // ... and their record headers
+    int32_t  scr[256];             // F: 8x8 transpose scratch / DC exchange
+    uint8_t  T[NTILE][17 * 32 + 16]; // K -> O: luma tiles: row 0 = top neighbours; byte 15 = left/corner, 16..31 samples; row 0 bytes 32..39 = up-right
+    uint8_t  Lcol[16];             // K: compact left neighbour column (luma)
+    uint8_t  E8[32];               // K: filtered Intra8x8 edge
+    uint8_t  TC[2][9 * 16];        // O: chroma tiles: row 0 = top; byte 7 = left/corner, 8..15 samples
+    uint8_t  LcolC[2][8];          // O: compact left neighbour columns (Cb, Cr)
+    uint8_t  SY[16 * 64];          // O: output strip: 4 macroblocks of reconstructed luma (flushed with wide stores)
+    uint8_t  SC[2][8 * 32];        // O: output strip: 4 macroblocks of Cb / Cr
+};
+
+__device__ __forceinline__ bool p1_wait(const int *ctr, int need, P1Ctl &C, uint32_t *err, int lane)
+{
+    int spins = 0;
+    while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < need) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > (1 << 22) || __hip_atomic_load(&C.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
+            if (lane == 0) { __hip_atomic_store(&C.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); atomicOr(err, 1u); }
+            return false;
+        }
+    }
+    asm volatile("" ::: "memory");
+    return true;
+}
+
+// one lane-uniform poll of seam granules: `act` lanes hold granule pointers; spins until every active lane's tag matches
+__device__ __forceinline__ bool p1_seam_poll(const unsigned long long *src, bool act, unsigned long long &v, uint32_t epoch, P1Ctl &C,
+                                             uint32_t *err, int lane)
+{
+    int spins = 0;
+    while (__builtin_amdgcn_ballot_w64(act && (uint32_t)(v >> 32) != epoch) != 0) {
+        __builtin_amdgcn_s_sleep(2);
+        bool stop = ++spins > (1 << 20) || __hip_atomic_load(&C.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (!stop && (spins & 255) == 0) stop = __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+        if (stop) {
+            if (lane == 0) { __hip_atomic_store(&C.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); atomicOr(err, 1u); }
+            return false;
+        }
+        v = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return true;
+}
+
+// ---- the arithmetic of recon_rows_kernel (recon_kernels.hip), on explicit LDS pointers ----
+// Residual stage for a PAIR of horizontally adjacent macroblocks (residuals do not depend on neighbours, so
+// two macroblocks share one pass): lanes 0-23 own the 24 4x4 blocks of macroblock 0, lanes 24-47 those of
+// macroblock 1 (0-15 luma, 16-19 Cb, 20-23 Cr each).  The lane's 16 levels arrive in registers (cA, cB = the
+// two 16-byte halves of its block, prefetched straight from the packed record).  Luma 8x8 blocks: the four
+// lanes of an 8x8 block hold its rows (2i, 2i+1); rows are transformed in place, columns after an LDS transpose.
+struct PairCtl {
+    int kind[2], qpy[2], qpc_cb[2], qpc_cr[2];
+    bool need[2];
+    int dc_shift_from;   // ReconArgs::dc_shift_from
+};
+
+// SCALING: the weights of BlockLds::w4 / w8 are not all 16 (MVHP_PARAM_SCALING; its own instantiation, so that the flat
+// case keeps its three-class LevelScale in three registers)
+template <bool SCALING>
+__device__ __forceinline__ void residual_pair(int16_t (*Wres)[384], int32_t *Wscr, const P1Tables &B, int lane, const int4 cA, const int4 cB,
+                                              const PairCtl &pc)
+{
+    const int sel = (lane >= 24) ? 1 : 0;
+    const int b = lane - 24 * sel; // block index inside the lane's macroblock (valid for lane < 48)
+
+    // ---- luma 8x8 (transform_8x8_residual, h264_transform.c:1205-1383), one macroblock at a time ----
+#pragma unroll
+    for (int s8 = 0; s8 < 2; s8++) {
+        if (pc.kind[s8] != MVHP_KIND_I8x8 || !pc.need[s8]) continue;
+        const int qpy = pc.qpy[s8];
+        const int m = qpy % 6, s = qpy / 6;
+        if (lane >= 24 * s8 && lane < 24 * s8 + 16) {
+            const int blk = b >> 2, r0 = (b & 3) * 2;
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const int row = r0 + h;
+                int d[8];
+                unpack8(h ? cB : cA, d);
+                // LevelScale8x8: 16 * normAdjust, or weight * normAdjust (SCALING)
+                auto ls8 = [&](int j) {
+                    const int v = B.ls8[m * 6 + B.cls8[row * 8 + j]];
+                    return SCALING ? (v >> 4) * (int)B.w8[row * 8 + j] : v;
+                };
+                if (qpy > 35) {
+#pragma unroll
+                    for (int j = 0; j < 8; j++) d[j] = (int)((unsigned)(d[j] * ls8(j)) << ((s - 6) & 31));
+                } else {
+                    const int rnd = 1 << ((5 - s) & 31), sh = (6 - s) & 31;
+#pragma unroll
+                    for (int j = 0; j < 8; j++) d[j] = (d[j] * ls8(j) + rnd) >> sh;
+                }
+                if (row == 0) d[0] += 32; // rounding term of the final (m + 32) >> 6, see idct4x4
+                idct8_1d(d);
+#pragma unroll
+                for (int j = 0; j < 8; j++) Wscr[blk * 64 + row * 8 + j] = d[j];
+            }
+        }
+        WAVE_SYNC();
+        if (lane < 32) {
+            const int blk = lane >> 3, col = lane & 7;
+            int d[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) d[i] = Wscr[blk * 64 + i * 8 + col];
+            idct8_1d(d);
+            const int xO = (blk & 1) * 8, yO = (blk >> 1) * 8;
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+                Wres[s8][(yO + i) * 16 + xO + col] = (int16_t)(pack_res(d[i] >> 6, 0) & 0xffff);
+        }
+        WAVE_SYNC();
+    }
+
+    // ---- 4x4 blocks (transform_4x4_residual, h264_transform.c:1049-1191) ----
+    const int kind = sel ? pc.kind[1] : pc.kind[0];
+    const int qpy = sel ? pc.qpy[1] : pc.qpy[0];
+    const bool need = sel ? pc.need[1] : pc.need[0];
+    const int first = (kind == MVHP_KIND_I8x8) ? 16 : 0;
+    const bool act = (lane < 48) && (b >= first) && need;
+    const bool all_ge24 = (pc.qpy[0] > 23) && (pc.qpc_cb[0] > 23) && (pc.qpc_cr[0] > 23) && (pc.qpy[1] > 23) &&
+                          (pc.qpc_cb[1] > 23) && (pc.qpc_cr[1] > 23); // wave-uniform
+    int d[16];
+    if (act) {
+        unpack8(cA, d);
+        unpack8(cB, d + 8);
+        Wscr[lane] = d[0];
+    }
+    WAVE_SYNC();
+    if (act) {
+        const bool chroma = b >= 16;
+        const int qpc = (b >= 20) ? (sel ? pc.qpc_cr[1] : pc.qpc_cr[0]) : (sel ? pc.qpc_cb[1] : pc.qpc_cb[0]);
+        const int qP = chroma ? qpc : qpy;
+        const int m = qP % 6, s = qP / 6;
+        int lsA = B.ls4[m * 3 + 0];
+        const int lsB = B.ls4[m * 3 + 1], lsC = B.ls4[m * 3 + 2];
+        int lsw[16];   // SCALING: LevelScale4x4 per position = weight * normAdjust (plane: Y / Cb / Cr)
+        if (SCALING) {
+            const uint8_t *w = B.w4[chroma ? ((b >= 20) ? 2 : 1) : 0];
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const int r = i >> 2, c = i & 3;
+                const int ls = ((r & 1) == 0 && (c & 1) == 0) ? lsA : (((r & 1) && (c & 1)) ? lsB : lsC);
+                lsw[i] = (ls >> 4) * (int)w[i];
+            }
+            lsA = lsw[0];   // the DC transforms use LevelScale(qP % 6, 0, 0) of their plane (8.5.10, 8.5.11.2)
+        }
+        int dc = d[0];
+        const bool keep_dc = chroma || (kind == MVHP_KIND_I16x16);
+        if (chroma) {
+            // transform_2x2_chromadc, h264_transform.c:827-860, :924-936, :988-1005
+            const int base = 24 * sel + ((b >= 20) ? 20 : 16), k = b & 3;
+            const int c0 = Wscr[base], c1 = Wscr[base + 1], c2 = Wscr[base + 2], c3 = Wscr[base + 3];
+            int f = (k == 0) ? (c0 + c1 + c2 + c3) : (k == 1) ? (c0 - c1 + c2 - c3)
+                  : (k == 2) ? (c0 + c1 - c2 - c3) : (c0 - c1 - c2 + c3);
+            dc = (int)((unsigned)(f * lsA) << s) >> 5;
+        } else if (kind == MVHP_KIND_I16x16) {
+            // transform_16x16_lumadc, h264_transform.c:756-812 (incl. the `qP > 36` test)
+            const int bi = ((b >> 3) << 1) | ((b >> 1) & 1);   // block row of luma4x4BlkIdx
+            const int bj = (((b >> 2) & 1) << 1) | (b & 1);    // block column
+            int f = 0;
+#pragma unroll
+            for (int q = 0; q < 16; q++) {
+                const int ri = ((q >> 3) << 1) | ((q >> 1) & 1), rj = (((q >> 2) & 1) << 1) | (q & 1);
+                const int v = Wscr[24 * sel + q];            // c[ri][rj]
+                f += (hneg(bi, ri) != hneg(rj, bj)) ? -v : v; // H4[bi][ri] * c * H4[rj][bj]
+            }
+            if (qpy >= pc.dc_shift_from) dc = (int)((unsigned)(f * lsA) << ((s - 6) & 31));
+            else dc = (int)((unsigned)(f * lsA) + (1u << ((5 - s) & 31))) >> ((6 - s) & 31);
+        }
+        // quant4x4, h264_transform.c:1100-1134.  qP differs between lanes, so the two cases are merged:
+        // ((c*LS + rnd) >> shr) << shl with (shr, rnd) = (0, 0) when qP > 23.
+        if (all_ge24) {
+            const int shl = s - 4;
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const int r = i >> 2, c = i & 3;
+                const int ls = SCALING ? lsw[i] : (((r & 1) == 0 && (c & 1) == 0) ? lsA : (((r & 1) && (c & 1)) ? lsB : lsC));
+                d[i] = (int)((unsigned)(d[i] * ls) << shl);
+            }
+        } else {
+            const int shl = max(s - 4, 0), shr = max(4 - s, 0), rnd = (1 << shr) >> 1;
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const int r = i >> 2, c = i & 3;
+                const int ls = SCALING ? lsw[i] : (((r & 1) == 0 && (c & 1) == 0) ? lsA : (((r & 1) && (c & 1)) ? lsB : lsC));
+                d[i] = (int)((unsigned)((d[i] * ls + rnd) >> shr) << shl);
+            }
+        }
+        if (keep_dc) d[0] = dc;
+        d[0] += 32;
+        idct4x4(d);
+        int base, stride;
+        if (!chroma) {
+            const int xO = (((b >> 2) & 1) << 3) | ((b & 1) << 2);
+            const int yO = ((b >> 3) << 3) | (((b >> 1) & 1) << 2);
+            base = yO * 16 + xO; stride = 16;
+        } else {
+            const int k = b & 3;
+            base = 256 + ((b >= 20) ? 64 : 0) + (k >> 1) * 32 + (k & 1) * 4; stride = 8;
+        }
+        int16_t *res = Wres[sel];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            int2 pk;
+            pk.x = pack_res(d[i * 4 + 0], d[i * 4 + 1]);
+            pk.y = pack_res(d[i * 4 + 2], d[i * 4 + 3]);
+            *reinterpret_cast<int2 *>(&res[base + i * stride]) = pk;
+        }
+    }
+    WAVE_SYNC();
+}
+
+// ---------------------------------------------------------------------------
+// prediction helpers
+// ---------------------------------------------------------------------------
+// Availability of the neighbours of the 16 luma 4x4 blocks, one bit per luma4x4BlkIdx
+// (deriv_neighbouringlocations by geometry, h264_spatial.c:739-786; the blkIdx 3/11 rule of
+// h264_intra_prediction.c:410-412).
+struct Avail4 { uint32_t left, up, upleft, upright; };
+__device__ __forceinline__ Avail4 avail4(bool A, bool Bv, bool C, bool D)
+{
+    constexpr uint32_t X0 = (1u << 0) | (1u << 2) | (1u << 8) | (1u << 10);   // blocks with xO == 0
+    constexpr uint32_t Y0 = (1u << 0) | (1u << 1) | (1u << 4) | (1u << 5);    // blocks with yO == 0
+    Avail4 a;
+    a.left = A ? 0xffffu : (0xffffu & ~X0);
+    a.up = Bv ? 0xffffu : (0xffffu & ~Y0);
+    a.upleft = (0xffffu & ~(X0 | Y0)) | (Bv ? ((1u << 1) | (1u << 4) | (1u << 5)) : 0u) |
+               (A ? ((1u << 2) | (1u << 8) | (1u << 10)) : 0u) | (D ? 1u : 0u);
+    a.upright = ((1u << 2) | (1u << 6) | (1u << 8) | (1u << 9) | (1u << 10) | (1u << 12) | (1u << 14)) |
+                (Bv ? ((1u << 0) | (1u << 1) | (1u << 4)) : 0u) | (C ? (1u << 5) : 0u);
+    return a;
+}
+
+// Intra 4x4 macroblock: 16 dependent block steps, lanes 0..15 own one sample each.
+// h264_intra_prediction.c:161-177, :315-483, :496-960 + transform4x4_luma (h264_transform.c:121-156).
+__device__ __forceinline__ void predict_mb_4x4(uint8_t *WT, const P1Tables &B, int lane, uint32_t m0, uint32_t m1,
+                                               uint32_t m2, uint32_t m3, bool A, bool Bv, bool C, bool D, bool has_res,
+                                               const int16_t *res)
+{
+    const Avail4 av = avail4(A, Bv, C, D);
+    // neighbours each mode needs, 3 bits per mode: bit0 left, bit1 up, bit2 up-left (mode 2 = DC handled apart)
+    constexpr uint32_t REQ = (2u << 0) | (1u << 3) | (0u << 6) | (2u << 9) | (7u << 12) | (7u << 15) | (7u << 18) |
+                             (2u << 21) | (1u << 24);
+    const int rmask = has_res ? -1 : 0;
+    // Per-block control word, computed once by lane b for block b (16 lanes in parallel) and handed to the
+    // block steps with v_readlane: bits 0-1 left/up available, bit 2 mode is DC, bit 3 prediction allowed,
+    // bits 8.. byte offset of the block's row in the tap table.
+    uint32_t info;
+    {
+        const int b = lane & 15;
+        const uint32_t mw = (b < 4) ? m0 : (b < 8) ? m1 : (b < 12) ? m2 : m3;
+        const uint32_t mode = (mw >> ((b & 3) * 8)) & 255u;
+        const uint32_t avail = ((av.left >> b) & 1u) | (((av.up >> b) & 1u) << 1) | (((av.upleft >> b) & 1u) << 2);
+        const uint32_t req = (REQ >> (min(mode, 8u) * 3)) & 7u;
+        const uint32_t ok = (((req & ~avail) == 0u) && (mode < 9u)) ? 1u : 0u; // else the prediction stays 0 (:442)
+        const uint32_t trow = (((av.upright >> b) & 1u) ? 0u : 9u) + min(mode, 8u);
+        info = (avail & 3u) | ((mode == 2u) ? 4u : 0u) | (ok << 3) | ((trow * 64u) << 8);
+    }
+    if (lane < 16) {
+        const int pix = (lane >> 2) * 32 + (lane & 3);   // this lane's sample inside a block, tile units
+        const int rpix = (lane >> 2) * 16 + (lane & 3);  // same in the residual array
+        const uint8_t *T = WT;
+        const uint8_t *tapb = reinterpret_cast<const uint8_t *>(B.tap4) + lane * 4;
+        // software pipeline: the table entry and the residual of block b+1 are fetched before block b's
+        // dependent tile reads, so only (tile read -> combine -> tile write) sits on the per-block chain
+        uint32_t inf = __builtin_amdgcn_readlane(info, 0);
+        uint32_t e_nx = *reinterpret_cast<const uint32_t *>(tapb + (inf >> 8));
+        int r_nx = (int)res[rpix];
+#pragma unroll
+        for (int blk = 0; blk < 16; blk++) {
+            const int xO = (((blk >> 2) & 1) << 3) | ((blk & 1) << 2);
+            const int yO = ((blk >> 3) << 3) | (((blk >> 1) & 1) << 2);
+            const int base = (yO + 1) * 32 + 16 + xO;     // tile index of the block's top-left sample
+            const uint32_t cur = inf;
+            const uint32_t e = e_nx;
+            const int r = r_nx & rmask;
+            if (blk < 15) {
+                const int nb = blk + 1;
+                const int nxO = (((nb >> 2) & 1) << 3) | ((nb & 1) << 2), nyO = ((nb >> 3) << 3) | (((nb >> 1) & 1) << 2);
+                inf = __builtin_amdgcn_readlane(info, nb);
+                e_nx = *reinterpret_cast<const uint32_t *>(tapb + (inf >> 8));
+                r_nx = (int)res[nyO * 16 + nxO + rpix];
+            }
+            int pred;
+            if (cur & 4u) { // DC
+                const int sumH = sum4(*reinterpret_cast<const uint32_t *>(&T[base - 32]));
+                const int sumV = T[base - 1] + T[base + 31] + T[base + 63] + T[base + 95];
+                const uint32_t lu = cur & 3u; // 3 both, 1 left only, 2 up only, 0 none
+                const int both = (sumH + sumV + 4) >> 3, l = (sumV + 2) >> 2, u = (sumH + 2) >> 2;
+                pred = (lu == 3u) ? both : (lu == 1u) ? l : (lu == 2u) ? u : 128;
+            } else {
+                const int okmask = (cur & 8u) ? -1 : 0;
+                const int a = T[base - 33 + (int)(e & 255)];
+                const int b = T[base - 33 + (int)((e >> 8) & 255)];
+                const int c = T[base - 33 + (int)(e >> 16)];
+                pred = ((a + 2 * b + c + 2) >> 2) & okmask;
+            }
+            WT[base + pix] = (uint8_t)clip255(pred + r);
+            WAVE_SYNC();
+        }
+    }
+    WAVE_SYNC();
+}
+
+// Intra 8x8 block: edge filtering by lanes 0..27, prediction by all 64 lanes.
+// h264_intra_prediction.c:1107-1353 + :1366-1793 + transform8x8_luma.
+__device__ __forceinline__ void predict_8x8(uint8_t *WT, uint8_t *WE8, const P1Tables &B, int lane, int blk, int mode,
+                                            bool A, bool Bv, bool C, bool D, bool has_res, const int16_t *res)
+{
+    const int xO = (blk & 1) * 8, yO = (blk >> 1) * 8;
+    const bool left = (xO > 0) || A;
+    const bool up = (yO > 0) || Bv;
+    const bool upleft = (xO > 0) ? ((yO > 0) || Bv) : ((yO > 0) ? A : D);
+    const bool upright = (blk == 0) ? Bv : (blk == 1) ? C : (blk == 2);
+    const uint8_t *Trow = &WT[yO * 32 + 16 + xO];
+    const uint8_t *Tcol = &WT[(yO + 1) * 32 + 15 + xO];
+    if (lane < 28) {
+        // raw edge sample for EE8 index e: e<=9: left[9-e] (clamped), 10: corner, >=11: top[e-11]
+        const int e = min(max(lane, 2), 26);
+        const int maxi = upright ? 15 : 7;
+        int lo = e - 1, hi = e + 1;
+        if (e == 2 || (e == 11 && !upleft) || (e == 10 && !left)) lo = e;
+        if (e == 26 || (e == 9 && !upleft) || (e == 10 && !up)) hi = e;
+        int v[3];
+        const int idxs[3] = {lo, e, hi};
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+            const int idx = idxs[q];
+            int a;
+            if (idx >= 10) a = (int)Trow[min(idx - 11, maxi)];
+            else a = (int)Tcol[(9 - idx) * 32];
+            v[q] = a;
+        }
+        WE8[lane] = (uint8_t)((v[0] + 2 * v[1] + v[2] + 2) >> 2);
+    }
+    WAVE_SYNC();
+    {
+        const int x = lane & 7, y = lane >> 3;
+        int pred = 0;
+        if (mode == 2) {
+            const uint32_t *E = reinterpret_cast<const uint32_t *>(WE8);
+            const uint32_t w0 = E[0], w1 = E[1], w2 = E[2], w3 = E[3], w4 = E[4];
+            const int sumV = sum4(w0 & 0xffff0000u) + sum4(w1) + sum4(w2 & 0x0000ffffu);       // E8[2..9]
+            const int sumH = sum4(w2 & 0xff000000u) + sum4(w3) + sum4(w4 & 0x00ffffffu);       // E8[11..18]
+            if (left && up) pred = (sumH + sumV + 8) >> 4;
+            else if (left) pred = (sumV + 4) >> 3;
+            else if (up) pred = (sumH + 4) >> 3;
+            else pred = 128;
+        } else {
+            bool ok;
+            switch (mode) {
+            case 0: case 3: case 7: ok = up; break;
+            case 1: case 8: ok = left; break;
+            default: ok = left && up && upleft; break;
+            }
+            if (ok && mode < 9) {
+                const uint32_t e = B.tap8[mode * 64 + lane];
+                const int v0 = WE8[e & 255], v1 = WE8[(e >> 8) & 255], v2 = WE8[e >> 16];
+                pred = (v0 + 2 * v1 + v2 + 2) >> 2;
+            }
+        }
+        const int r = has_res ? (int)res[(yO + y) * 16 + xO + x] : 0;
+        WT[(yO + y + 1) * 32 + 16 + xO + x] = (uint8_t)clip255(pred + r);
+    }
+    WAVE_SYNC();
+}
+
+// Intra 16x16: 64 lanes x 4 samples. h264_intra_prediction.c:1809-2141 + transform16x16_luma.
+// D: the up-left macroblock is available -- it always is when A and Bv are, except across a slice boundary, where the
+// reference's code reads the corner as 0 (h264_intra_prediction.c:1839-1846: phv stays 0); a conforming stream never
+// predicts Plane there
+__device__ __forceinline__ void predict_16x16(uint8_t *WT, const uint8_t *WLcol, int lane, int mode, bool A, bool Bv, bool D, bool has_res,
+                                              const int16_t *res)
+{
+    const int y = lane >> 2, x0 = (lane & 3) * 4;
+    const bool left = A, up = Bv;
+    const uint4 topv = *reinterpret_cast<const uint4 *>(&WT[16]);
+    const uint4 lefv = *reinterpret_cast<const uint4 *>(WLcol);
+    int p[4] = {0, 0, 0, 0};
+    if (mode == 0) {
+        if (up) {
+            const uint32_t w = (lane & 3) == 0 ? topv.x : (lane & 3) == 1 ? topv.y : (lane & 3) == 2 ? topv.z : topv.w;
+            p[0] = w & 255; p[1] = (w >> 8) & 255; p[2] = (w >> 16) & 255; p[3] = w >> 24;
+        }
+    } else if (mode == 1) {
+        if (left) { const int v = WLcol[y]; p[0] = p[1] = p[2] = p[3] = v; }
+    } else if (mode == 2) {
+        const int sumH = sum4(topv.x) + sum4(topv.y) + sum4(topv.z) + sum4(topv.w);
+        const int sumV = sum4(lefv.x) + sum4(lefv.y) + sum4(lefv.z) + sum4(lefv.w);
+        int v;
+        if (left && up) v = (sumH + sumV + 16) >> 5;
+        else if (left) v = (sumV + 8) >> 4;
+        else if (up) v = (sumH + 8) >> 4;
+        else v = 128;
+        p[0] = p[1] = p[2] = p[3] = v;
+    } else if (mode == 3) {
+        if (left && up) {
+            const int cor = D ? (int)WT[15] : 0;
+            const uint32_t tw[4] = {topv.x, topv.y, topv.z, topv.w};
+            const uint32_t lw[4] = {lefv.x, lefv.y, lefv.z, lefv.w};
+            int H = 0, V = 0;
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const int hi = 8 + i, lo = 6 - i;
+                const int th = (tw[hi >> 2] >> ((hi & 3) * 8)) & 255;
+                const int lh = (lw[hi >> 2] >> ((hi & 3) * 8)) & 255;
+                const int tl = (lo < 0) ? cor : (int)((tw[lo >> 2] >> ((lo & 3) * 8)) & 255);
+                const int ll = (lo < 0) ? cor : (int)((lw[lo >> 2] >> ((lo & 3) * 8)) & 255);
+                H += (i + 1) * (th - tl);
+                V += (i + 1) * (lh - ll);
+            }
+            const int a = 16 * ((int)(lefv.w >> 24) + (int)(topv.w >> 24));
+            const int b = (5 * H + 32) >> 6;
+            const int c = (5 * V + 32) >> 6;
+#pragma unroll
+            for (int q = 0; q < 4; q++) p[q] = clip255((a + b * (x0 + q - 7) + c * (y - 7) + 16) >> 5);
+        }
+    }
+    if (has_res) {
+        const int2 rr = *reinterpret_cast<const int2 *>(&res[y * 16 + x0]);
+        p[0] += (int16_t)(rr.x & 0xffff); p[1] += rr.x >> 16;
+        p[2] += (int16_t)(rr.y & 0xffff); p[3] += rr.y >> 16;
+    }
+    const uint32_t out = (uint32_t)clip255(p[0]) | ((uint32_t)clip255(p[1]) << 8) |
+                         ((uint32_t)clip255(p[2]) << 16) | ((uint32_t)clip255(p[3]) << 24);
+    *reinterpret_cast<uint32_t *>(&WT[(y + 1) * 32 + 16 + x0]) = out;
+    WAVE_SYNC();
+}
+
+// Chroma, both planes: lane -> plane = lane>>5, y = (lane&31)>>2, x0 = (lane&3)*2.
+// h264_intra_prediction.c:2157-2564 + transform4x4_chroma.
+__device__ __forceinline__ void predict_chroma(uint8_t (*WTC)[9 * 16], uint8_t (*WLcolC)[8], int lane, int mode, bool A, bool Bv, bool D, bool has_res,
+                                               const int16_t *res)
+{
+    const int pl = lane >> 5, y = (lane & 31) >> 2, x0 = (lane & 3) * 2;
+    const bool left = A, up = Bv;
+    const uint8_t *TC = WTC[pl];
+    const uint2 topv = *reinterpret_cast<const uint2 *>(&TC[8]);
+    const uint2 lefv = *reinterpret_cast<const uint2 *>(WLcolC[pl]);
+    int p0 = 0, p1 = 0;
+    if (mode == 0) {
+        const int bx = x0 >> 2, by = y >> 2;
+        const int sH = sum4(bx ? topv.y : topv.x), sV = sum4(by ? lefv.y : lefv.x);
+        int v;
+        if (!left && !up) v = 128;
+        else if (bx == by) {
+            if (left && up) v = (sH + sV + 4) >> 3;
+            else if (left) v = (sV + 2) >> 2;
+            else v = (sH + 2) >> 2;
+        } else if (bx == 1) { // xO > 0, yO == 0: prefers top
+            v = up ? ((sH + 2) >> 2) : ((sV + 2) >> 2);
+        } else {              // xO == 0, yO > 0: prefers left
+            v = left ? ((sV + 2) >> 2) : ((sH + 2) >> 2);
+        }
+        p0 = p1 = v;
+    } else if (mode == 1) {
+        if (left) p0 = p1 = WLcolC[pl][y];
+    } else if (mode == 2) {
+        if (up) { p0 = TC[8 + x0]; p1 = TC[8 + x0 + 1]; }
+    } else if (mode == 3) {
+        if (left && up) {
+            const int cor = D ? (int)TC[7] : 0;
+            const uint32_t tw[2] = {topv.x, topv.y}, lw[2] = {lefv.x, lefv.y};
+            int H = 0, V = 0;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int hi = 4 + i, lo = 2 - i;
+                const int th = (tw[hi >> 2] >> ((hi & 3) * 8)) & 255;
+                const int lh = (lw[hi >> 2] >> ((hi & 3) * 8)) & 255;
+                const int tl = (lo < 0) ? cor : (int)((tw[0] >> (lo * 8)) & 255);
+                const int ll = (lo < 0) ? cor : (int)((lw[0] >> (lo * 8)) & 255);
+                H += (i + 1) * (th - tl);
+                V += (i + 1) * (lh - ll);
+            }
+            const int a = 16 * ((int)(lefv.y >> 24) + (int)(topv.y >> 24));
+            const int b = (34 * H + 32) >> 6;
+            const int c = (34 * V + 32) >> 6;
+            p0 = clip255((a + b * (x0 - 3) + c * (y - 3) + 16) >> 5);
+            p1 = clip255((a + b * (x0 + 1 - 3) + c * (y - 3) + 16) >> 5);
+        }
+    }
+    if (has_res) {
+        const int rr = *reinterpret_cast<const int *>(&res[256 + pl * 64 + y * 8 + x0]);
+        p0 += (int16_t)(rr & 0xffff); p1 += rr >> 16;
+    }
+    const uint16_t out = (uint16_t)(clip255(p0) | (clip255(p1) << 8));
+    *reinterpret_cast<uint16_t *>(&WTC[pl][(y + 1) * 16 + 8 + x0]) = out;
+    WAVE_SYNC();
+}
+
+
+template <int R, bool EXT>
+__global__ __launch_bounds__(R * 3 * 64) void recon_pipe1_kernel(ReconArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int W = a.width_mbs, H = a.height_mbs;
+    P1Tables &B = *reinterpret_cast<P1Tables *>(smem);
+    P1Ctl &C = *reinterpret_cast<P1Ctl *>(smem + sizeof(P1Tables));
+    uint8_t *line_y = smem + sizeof(P1Tables) + sizeof(P1Ctl);
+    uint8_t *line_cb = line_y + W * 16;
+    uint8_t *line_cr = line_cb + W * 8;
+    P1Row *rows = reinterpret_cast<P1Row *>(line_cr + W * 8);
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int role = wave / R, r = wave - role * R;     // role 0 = F, 1 = K, 2 = O of row r of the band
+    const int lane_c = threadIdx.x & 63;
+    constexpr int NT = R * 3 * 64;
+
+    if (threadIdx.x == 0) C.unit = (int)(atomicAdd(a.wide_ticket, 1u) - a.wide_base);
+    // ---- one-time table setup (as recon_rows_kernel) ----
+    for (int i = threadIdx.x; i < 18; i += NT) B.ls4[i] = 16 * c_v4x4[i];
+    for (int i = threadIdx.x; i < 36; i += NT) B.ls8[i] = 16 * c_v8x8[i];
+    for (int i = threadIdx.x; i < 64; i += NT) {
+        const int rr = i >> 3, c = i & 7;
+        int k;
+        if ((rr % 4 == 0) && (c % 4 == 0)) k = 0;
+        else if ((rr % 2 == 1) && (c % 2 == 1)) k = 1;
+        else if ((rr % 4 == 2) && (c % 4 == 2)) k = 2;
+        else if (((rr % 4 == 0) && (c % 2 == 1)) || ((rr % 2 == 1) && (c % 4 == 0))) k = 3;
+        else if (((rr % 4 == 0) && (c % 4 == 2)) || ((rr % 4 == 2) && (c % 4 == 0))) k = 4;
+        else k = 5;
+        B.cls8[i] = (uint8_t)k;
+    }
+    for (int i = threadIdx.x; i < 2 * 9 * 16; i += NT)
+        B.tap4[i] = tap4_entry((i >> 4) % 9, i & 3, (i >> 2) & 3, i >= 9 * 16);
+    for (int i = threadIdx.x; i < 9 * 64; i += NT) B.tap8[i] = tap8_entry(i >> 6, i & 7, (i >> 3) & 7);
+    if (EXT)
+        for (int i = threadIdx.x; i < 112; i += NT) (&B.w4[0][0])[i] = a.scaling ? a.weights[i] : (uint8_t)16;   // w4 | w8 are adjacent
+    if (threadIdx.x < ROWS_MAX) { C.f_done[threadIdx.x] = 0; C.k_done[threadIdx.x] = 0; C.o_done[threadIdx.x] = 0; C.c_done[threadIdx.x] = 0; }
+    if (threadIdx.x == 16) C.abort_flag = 0;
+    __syncthreads();
+
+    // this workgroup's picture and band (band-major tickets: see recon_rows_kernel)
+    const int bands = (H + R - 1) / R;
+    const int unit = __builtin_amdgcn_readfirstlane(C.unit);
+    const int band = unit / a.n_frames;
+    const int frame = unit - band * a.n_frames;
+    if ((unsigned)band >= (unsigned)bands) return;   // (cannot happen: the grid has n_frames * bands workgroups)
+    const int row = band * R + r;
+    if (row >= H) return;                            // the three waves of a row beyond the picture
+    P1Row &Rw = rows[r];
+    const bool BvG = row > 0;                        // the row above exists: what the waits and the fetches go by
+    const bool seam_in = (r == 0) && band > 0;       // top neighbours of this row come from the seam above
+    const bool seam_out = (r == R - 1) && (row + 1 < H);
+    const unsigned long long *seam_rd = seam_in ? a.seam + (size_t)(frame * (bands - 1) + band - 1) * W * SEAM_GRANULES : nullptr;
+    unsigned long long *seam_wr = seam_out ? a.seam + (size_t)(frame * (bands - 1) + band) * W * SEAM_GRANULES : nullptr;
+    const unsigned long long seam_tag = (unsigned long long)a.wide_epoch << 32;
+
+    if (role == 0) {
+        // =========================================================================================================
+        // F: records -> residuals of a macroblock pair (residual_pair: lanes 0-23 own the 24 4x4 blocks of macroblock 0,
+        //    lanes 24-47 those of macroblock 1; lanes 48-51 carry the two 32-byte headers)
+        // =========================================================================================================
+        const uint8_t *fpacked = a.packed + (size_t)frame * W * H * MVHP_MB_BYTES;
+        int4 pA = make_int4(0, 0, 0, 0), pB = make_int4(0, 0, 0, 0);
+        auto prefetch = [&](int px, int lane_p) {
+            pA = make_int4(0, 0, 0, 0);
+            pB = make_int4(0, 0, 0, 0);
+            if (px >= W) return;
+            const uint8_t *rec0 = fpacked + (size_t)(row * W + px) * MVHP_MB_BYTES;
+            const bool two = (px + 1) < W;
+            const uint8_t *src = nullptr;
+            if (lane_p < 24) src = rec0 + MVHP_MB_HEADER_BYTES + lane_p * 32;
+            else if (lane_p < 48) { if (two) src = rec0 + MVHP_MB_BYTES + MVHP_MB_HEADER_BYTES + (lane_p - 24) * 32; }
+            else if (lane_p < 50) src = rec0 + (lane_p - 48) * 16;
+            else if (lane_p < 52) { if (two) src = rec0 + MVHP_MB_BYTES + (lane_p - 50) * 16; }
+            if (src) {
+                pA = *reinterpret_cast<const int4 *>(src);
+                if (lane_p < 48) pB = *reinterpret_cast<const int4 *>(src + 16);
+            }
+        };
+        prefetch(0, lane_c);
+#pragma unroll 1
+        for (int mbx0 = 0; mbx0 < W; mbx0 += 2) {
+            const int npair = min(2, W - mbx0);
+            int lane = lane_c;
+            asm volatile("" : "+v"(lane));
+            const int4 cA = pA, cB = pB;
+            prefetch(mbx0 + 2, lane);
+            const int slot = (mbx0 >> 1) % NPAIR;
+            // the slot is free once K and O have finished with the pair NPAIR pairs back
+            if (!p1_wait(&C.k_done[r], mbx0 - 2 * NPAIR + 2, C, a.err, lane)) return;
+            if (!p1_wait(&C.o_done[r], mbx0 - 2 * NPAIR + 2, C, a.err, lane)) return;
+            // headers: wave-uniform -> scalars (v_readlane from the header lanes)
+            PairCtl pc;
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                const uint32_t hh0 = __builtin_amdgcn_readlane((uint32_t)cA.x, 48 + 2 * k);
+                const uint32_t hnz = __builtin_amdgcn_readlane((uint32_t)cA.z, 48 + 2 * k);
+                pc.kind[k] = hh0 & 255;
+                pc.qpy[k] = (hh0 >> 8) & 255;
+#pragma unroll
+                for (int c = 0; c < 2; c++) { // derivChromaQP, h264_transform.c:598-637
+                    int qpi = pc.qpy[k] + (c ? a.cqp_off_cr : a.cqp_off_cb);
+                    qpi = min(max(qpi, 0), 51);
+                    // Table 8-15 (h264_transform.c:71) as nibbles of (QPC - 29) for qPI = 30..51: scalar arithmetic only
+                    const unsigned long long lo = 0x9888776655433210ull, hi = 0xAAAA99ull; // qPI 30..45 | 46..51
+                    const int q = qpi - 30;
+                    const int nib = (int)(((q < 16) ? (lo >> ((q & 15) * 4)) : (hi >> (((q - 16) & 15) * 4))) & 15ull);
+                    const int v = (qpi > 29) ? 29 + nib : qpi;
+                    if (c) pc.qpc_cr[k] = v; else pc.qpc_cb[k] = v;
+                }
+                // Intra16x16 at QP'Y == 36 yields a non-zero DC term even from all-zero levels
+                // (h264_transform.c:797-808), so the residual stage cannot be skipped there.
+                const bool quirk36 = (pc.kind[k] == MVHP_KIND_I16x16) && (pc.qpy[k] == 36) && (a.dc_shift_from > 36);
+                const bool rl = ((hnz & 0xffffu) != 0) || quirk36;
+                const bool rc = (hnz & 0xff0000u) != 0;
+                pc.need[k] = (rl || rc) && (k < npair) && (pc.kind[k] != MVHP_KIND_IPCM);
+            }
+            pc.dc_shift_from = a.dc_shift_from;
+            if (pc.need[0] || pc.need[1]) residual_pair<EXT>(Rw.res[slot], Rw.scr, B, lane, cA, cB, pc);
+            // the headers for K and O (lanes 48-51: 16 bytes each); an I_PCM macroblock's samples travel in the residual area
+            // as the record holds them (32 bytes per block lane; K and O copy them out)
+            if (lane >= 48 && lane < 52) *reinterpret_cast<int4 *>(&Rw.hdr[slot][(lane - 48) >> 1][((lane - 48) & 1) * 4]) = cA;
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                if (pc.kind[k] == MVHP_KIND_IPCM && k < npair && lane >= 24 * k && lane < 24 * k + 16) {
+                    int16_t *dst = &Rw.res[slot][k][(lane - 24 * k) * 16];
+                    *reinterpret_cast<int4 *>(dst) = cA;
+                    *reinterpret_cast<int4 *>(dst + 8) = cB;
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (lane == 0) __hip_atomic_store(&C.f_done[r], mbx0 + npair, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            WAVE_SYNC();
+        }
+        return;
+    }
+
+    if (role == 1) {
+        // =========================================================================================================
+        // K: luma prediction + residual add (h264_intra_prediction.c:112-2141, transform*_luma), luma neighbour state, the row
+        //    dependency -- the chain every other row waits for, and nothing else
+        // =========================================================================================================
+        unsigned long long seam_pend = 0;
+        __builtin_amdgcn_s_setprio(2);
+#pragma unroll 1
+        for (int mbx = 0; mbx < W; mbx++) {
+            int lane = lane_c;
+            asm volatile("" : "+v"(lane));
+            const int slot = (mbx >> 1) % NPAIR, k = mbx & 1;
+            uint8_t *T = Rw.T[mbx % NTILE];
+            uint8_t *Tn = Rw.T[(mbx + 1) % NTILE];    // where the next macroblock of the row will be built
+
+            if (seam_in && (mbx & 1) == 0) {
+                // Macroblocks mbx and mbx + 1 read luma columns <= mbx + 2 of the row above: the first step of a row fetches columns
+                // 0..2 now; every later even step finds (mbx + 1, mbx + 2) asked for two steps ago, and asks for (mbx + 3, mbx + 4).
+                // Lane l: column c0 + (l >> 2), luma granule l & 3.
+                const int c0 = mbx ? mbx + 1 : 0, ncol = mbx ? 2 : 3;
+                const int col = c0 + (lane >> 2), g = lane & 3;
+                const bool act = (lane < ncol * 4) && (col < W);
+                const unsigned long long *src = seam_rd + (size_t)(act ? col : 0) * SEAM_GRANULES + g;
+                unsigned long long v = seam_pend;
+                if (mbx == 0) v = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (!p1_seam_poll(src, act, v, a.wide_epoch, C, a.err, lane)) return;
+                if (act) *reinterpret_cast<uint32_t *>(&line_y[col * 16 + g * 4]) = (uint32_t)v;
+                const int ncolumn = mbx + 3 + (lane >> 2);
+                if (lane < 8 && ncolumn < W)
+                    seam_pend = __hip_atomic_load(seam_rd + (size_t)ncolumn * SEAM_GRANULES + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                WAVE_SYNC();
+            }
+
+            // the tile is free once O has taken macroblock mbx - NTILE out of it; the residuals of mbx must be in the ring
+            if (!p1_wait(&C.o_done[r], mbx - NTILE + 1, C, a.err, lane)) return;
+            if (!p1_wait(&C.f_done[r], mbx + 1, C, a.err, lane)) return;
+            const int4 hA = *reinterpret_cast<const int4 *>(&Rw.hdr[slot][k][0]);
+            const int4 hB = *reinterpret_cast<const int4 *>(&Rw.hdr[slot][k][4]);
+            const uint32_t h0 = __builtin_amdgcn_readfirstlane((uint32_t)hA.x), h1 = __builtin_amdgcn_readfirstlane((uint32_t)hA.y);
+            const uint32_t hnz = __builtin_amdgcn_readfirstlane((uint32_t)hA.z);
+            const uint32_t m0 = __builtin_amdgcn_readfirstlane((uint32_t)hA.w), m1 = __builtin_amdgcn_readfirstlane((uint32_t)hB.x);
+            const uint32_t m2 = __builtin_amdgcn_readfirstlane((uint32_t)hB.y), m3 = __builtin_amdgcn_readfirstlane((uint32_t)hB.z);
+            const int kind = h0 & 255, qpy = (h0 >> 8) & 255;
+            const int i16mode = h1 & 255;
+            const bool quirk36 = (kind == MVHP_KIND_I16x16) && (qpy == 36) && (a.dc_shift_from > 36);
+            const bool res_luma = ((hnz & 0xffffu) != 0) || quirk36;
+            const int16_t *res = Rw.res[slot][k];
+            // neighbours: by geometry (h264_spatial.c:333-416), less those in another slice (MVHP_PARAM_SLICES: header byte 6)
+            const uint32_t un = (EXT && a.slices) ? ((h1 >> 16) & 255u) : 0u;
+            const bool A = (mbx > 0) && !(un & MVHP_UNAVAIL_A), Cav = BvG && (mbx < W - 1) && !(un & MVHP_UNAVAIL_C),
+                       D = (mbx > 0) && BvG && !(un & MVHP_UNAVAIL_D);
+            const bool Bv = BvG && !(un & MVHP_UNAVAIL_B);
+
+            // wait for the row above: needs columns <= min(mbx+1, W-1); then fetch the top neighbours
+            if (BvG) {
+                if (!seam_in && !p1_wait(&C.k_done[r - 1], min(mbx + 2, W), C, a.err, lane)) return;
+                // lanes 0-3 luma top, 4-5 luma up-right (when the column exists): one dword each
+                if (lane < 6 && ((mbx < W - 1) || lane < 4))
+                    *reinterpret_cast<uint32_t *>(&T[16 + lane * 4]) = *reinterpret_cast<const uint32_t *>(&line_y[mbx * 16 + lane * 4]);
+            }
+            WAVE_SYNC();
+
+            if (kind == MVHP_KIND_IPCM) {
+                // I_PCM (8.3.5; MVHP_STREAM_SPEC streams only): the owner of luma block 2j holds luma rows 2j and 2j+1
+                if (lane < 16 && (lane & 1) == 0) {
+                    const int jj = lane >> 1;
+                    *reinterpret_cast<int4 *>(&T[(2 * jj + 1) * 32 + 16]) = *reinterpret_cast<const int4 *>(&res[lane * 16]);
+                    *reinterpret_cast<int4 *>(&T[(2 * jj + 2) * 32 + 16]) = *reinterpret_cast<const int4 *>(&res[lane * 16 + 8]);
+                }
+                WAVE_SYNC();
+            } else if (kind == MVHP_KIND_I16x16) {
+                predict_16x16(T, Rw.Lcol, lane, i16mode, A, Bv, D, res_luma, res);
+            } else if (kind == MVHP_KIND_I4x4) {
+                predict_mb_4x4(T, B, lane, m0, m1, m2, m3, A, Bv, Cav, D, res_luma, res);
+            } else {
+                for (int blk = 0; blk < 4; blk++)
+                    predict_8x8(T, Rw.E8, B, lane, blk, (m0 >> (blk * 8)) & 255, A, Bv, Cav, D, res_luma, res);
+            }
+
+            // ---- luma neighbour state for the next macroblock (built in the NEXT tile) / the next row, then publish ----
+            {
+                // lane 0: corner (this macroblock's top-right sample); lanes 16-31: right column -> left column of the next tile +
+                // Lcol; lanes 48-51: bottom row -> line buffer (+ seam)
+                uint32_t keep = 0, bot = 0;
+                if (lane == 0) keep = T[31];
+                else if (lane >= 16 && lane < 32) keep = T[(lane - 15) * 32 + 31];
+                if (lane >= 48 && lane < 52) bot = *reinterpret_cast<const uint32_t *>(&T[16 * 32 + 16 + (lane - 48) * 4]);
+                WAVE_SYNC();
+                if (lane == 0) Tn[15] = (uint8_t)keep;
+                else if (lane >= 16 && lane < 32) { Tn[(lane - 15) * 32 + 15] = (uint8_t)keep; Rw.Lcol[lane - 16] = (uint8_t)keep; }
+                if (lane >= 48 && lane < 52) {
+                    *reinterpret_cast<uint32_t *>(&line_y[mbx * 16 + (lane - 48) * 4]) = bot;
+                    if (seam_out)   // the same four dwords, tagged, to the band below (one write-through store per granule)
+                        __hip_atomic_store(seam_wr + (size_t)mbx * SEAM_GRANULES + (lane - 48), seam_tag | bot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (lane == 0) __hip_atomic_store(&C.k_done[r], mbx + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            WAVE_SYNC();
+        }
+        return;
+    }
+
+    // =============================================================================================================
+    // O: chroma prediction (h264_intra_prediction.c:2157-2564 + transform4x4_chroma; one macroblock behind the row above's O)
+    //    and write-out: the macroblock joins a 4-macroblock output strip in LDS; full strips go to HBM as 64-byte luma /
+    //    32-byte chroma row segments plus (fused) the RGB conversion (export.c:65-188, export_utils.c:209-324)
+    // =============================================================================================================
+    {
+        uint8_t *fy = a.yuv + (size_t)frame * W * H * 384;
+        uint8_t *fcb = fy + (size_t)W * H * 256;
+        uint8_t *fcr = fcb + (size_t)W * H * 64;
+        uint8_t *frgb = a.rgb ? a.rgb + (size_t)frame * W * H * 768 : nullptr;
+        const int pitch = W * 16, cpitch = W * 8;
+        unsigned long long seam_pend = 0;
+#pragma unroll 1
+        for (int mbx = 0; mbx < W; mbx++) {
+            int lane = lane_c;
+            asm volatile("" : "+v"(lane));
+            const int slot = (mbx >> 1) % NPAIR, k = mbx & 1;
+            const uint8_t *T = Rw.T[mbx % NTILE];
+
+            if (seam_in && (mbx & 1) == 0) {
+                // Macroblocks mbx and mbx + 1 read chroma columns mbx and mbx + 1 of the row above: the first step fetches (0, 1) now;
+                // every later even step finds its two columns asked for two steps ago, and asks for (mbx + 2, mbx + 3).
+                // Lane l < 8: column mbx + (l >> 2), granule 4 + (l & 3) (4-5 Cb dwords, 6-7 Cr).
+                const int g = 4 + (lane & 3);
+                const int col = mbx + ((lane >> 2) & 1);
+                const bool act = (lane < 8) && (col < W);
+                const unsigned long long *src = seam_rd + (size_t)(act ? col : 0) * SEAM_GRANULES + g;
+                unsigned long long v = seam_pend;
+                if (mbx == 0) v = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (!p1_seam_poll(src, act, v, a.wide_epoch, C, a.err, lane)) return;
+                if (act) {
+                    uint8_t *dst = (g < 6) ? &line_cb[col * 8 + (g - 4) * 4] : &line_cr[col * 8 + (g - 6) * 4];
+                    *reinterpret_cast<uint32_t *>(dst) = (uint32_t)v;
+                }
+                const int ncol = mbx + 2 + ((lane >> 2) & 1);
+                if (lane < 8 && ncol < W)
+                    seam_pend = __hip_atomic_load(seam_rd + (size_t)ncol * SEAM_GRANULES + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                WAVE_SYNC();
+            }
+
+            // header and chroma residuals of this macroblock; the row above's chroma of this column
+            if (!p1_wait(&C.f_done[r], mbx + 1, C, a.err, lane)) return;
+            const uint32_t h0 = __builtin_amdgcn_readfirstlane(Rw.hdr[slot][k][0]), h1 = __builtin_amdgcn_readfirstlane(Rw.hdr[slot][k][1]);
+            const uint32_t hnz = __builtin_amdgcn_readfirstlane(Rw.hdr[slot][k][2]);
+            const int kind = h0 & 255;
+            const int cmode = (h0 >> 24) & 255;
+            const bool res_chroma = (hnz & 0xff0000u) != 0 && kind != MVHP_KIND_IPCM;
+            const int16_t *res = Rw.res[slot][k];
+            const uint32_t un = (EXT && a.slices) ? ((h1 >> 16) & 255u) : 0u;
+            const bool A = (mbx > 0) && !(un & MVHP_UNAVAIL_A), D = (mbx > 0) && BvG && !(un & MVHP_UNAVAIL_D);
+            const bool Bv = BvG && !(un & MVHP_UNAVAIL_B);
+            if (BvG) {
+                if (!seam_in && !p1_wait(&C.c_done[r - 1], mbx + 1, C, a.err, lane)) return;
+                if (lane < 4) {   // lanes 0-1 Cb top, 2-3 Cr top: one dword each
+                    const uint8_t *src = (lane < 2) ? &line_cb[mbx * 8 + lane * 4] : &line_cr[mbx * 8 + (lane - 2) * 4];
+                    *reinterpret_cast<uint32_t *>(&Rw.TC[lane >> 1][8 + (lane & 1) * 4]) = *reinterpret_cast<const uint32_t *>(src);
+                }
+            }
+            WAVE_SYNC();
+            predict_chroma(Rw.TC, Rw.LcolC, lane, cmode, A, Bv, D, res_chroma, res);
+            if (kind == MVHP_KIND_IPCM) {
+                // I_PCM: the owner of luma block 2j + 1 holds Cb row j and Cr row j, over what the prediction made
+                if (lane < 16 && (lane & 1)) {
+                    const int jj = lane >> 1;
+                    const int4 sA = *reinterpret_cast<const int4 *>(&res[lane * 16]);
+                    *reinterpret_cast<int2 *>(&Rw.TC[0][(jj + 1) * 16 + 8]) = make_int2(sA.x, sA.y);
+                    *reinterpret_cast<int2 *>(&Rw.TC[1][(jj + 1) * 16 + 8]) = make_int2(sA.z, sA.w);
+                }
+                WAVE_SYNC();
+            }
+
+            // ---- the luma of this macroblock: into the strip ----
+            if (!p1_wait(&C.k_done[r], mbx + 1, C, a.err, lane)) return;
+            const int mbi = mbx & 3;
+            {
+                const int y = lane >> 2, q = lane & 3;
+                *reinterpret_cast<uint32_t *>(&Rw.SY[y * 64 + mbi * 16 + q * 4]) = *reinterpret_cast<const uint32_t *>(&T[(y + 1) * 32 + 16 + q * 4]);
+                if (lane < 32) {
+                    const int pl = lane >> 4, cy = (lane & 15) >> 1, hf = lane & 1;
+                    *reinterpret_cast<uint32_t *>(&Rw.SC[pl][cy * 32 + mbi * 8 + hf * 4]) =
+                        *reinterpret_cast<const uint32_t *>(&Rw.TC[pl][(cy + 1) * 16 + 8 + hf * 4]);
+                }
+            }
+            // the luma tile and the ring slot have been read: K may build macroblock mbx + NTILE in the tile, F may refill the slot
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (lane == 0) __hip_atomic_store(&C.o_done[r], mbx + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+
+            // ---- chroma neighbour state for the next macroblock / the next row, then publish the chroma ----
+            {
+                // lanes 1-2: corners; lanes 32-47: right columns -> left columns + LcolC; lanes 52-55: bottom rows -> line buffer
+                uint32_t keep = 0, bot = 0;
+                uint8_t *bdst = line_cb;
+                if (lane == 1 || lane == 2) keep = Rw.TC[lane - 1][15];
+                else if (lane >= 32 && lane < 48) keep = Rw.TC[(lane - 32) >> 3][(((lane - 32) & 7) + 1) * 16 + 15];
+                if (lane >= 52 && lane < 54) { bot = *reinterpret_cast<const uint32_t *>(&Rw.TC[0][8 * 16 + 8 + (lane - 52) * 4]); bdst = &line_cb[mbx * 8 + (lane - 52) * 4]; }
+                else if (lane >= 54 && lane < 56) { bot = *reinterpret_cast<const uint32_t *>(&Rw.TC[1][8 * 16 + 8 + (lane - 54) * 4]); bdst = &line_cr[mbx * 8 + (lane - 54) * 4]; }
+                WAVE_SYNC();
+                if (lane == 1 || lane == 2) Rw.TC[lane - 1][7] = (uint8_t)keep;
+                else if (lane >= 32 && lane < 48) {
+                    const int pl = (lane - 32) >> 3, cy = (lane - 32) & 7;
+                    Rw.TC[pl][(cy + 1) * 16 + 7] = (uint8_t)keep;
+                    Rw.LcolC[pl][cy] = (uint8_t)keep;
+                }
+                if (lane >= 52 && lane < 56) {
+                    *reinterpret_cast<uint32_t *>(bdst) = bot;
+                    if (seam_out)   // granules 4-7 of the column, tagged, to the band below
+                        __hip_atomic_store(seam_wr + (size_t)mbx * SEAM_GRANULES + (lane - 48), seam_tag | bot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (lane == 0) __hip_atomic_store(&C.c_done[r], mbx + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+
+            if (mbi == 3 || mbx == W - 1) {
+                WAVE_SYNC();
+                const int x0 = mbx - mbi, nb = (mbi + 1) * 16; // strip origin (MB units), width in samples
+                {   // luma: lane -> 16 bytes of one row
+                    const int y = lane >> 2, part = (lane & 3) * 16;
+                    if (part < nb)
+                        *reinterpret_cast<uint4 *>(&fy[(size_t)(row * 16 + y) * pitch + x0 * 16 + part]) =
+                            *reinterpret_cast<const uint4 *>(&Rw.SY[y * 64 + part]);
+                }
+                {   // chroma: lane -> 8 bytes of one row of one plane
+                    const int pl = lane >> 5, cy = (lane >> 2) & 7, part = (lane & 3) * 8;
+                    if (part < (nb >> 1))
+                        *reinterpret_cast<uint2 *>((pl ? fcr : fcb) + (size_t)(row * 8 + cy) * cpitch + x0 * 8 + part) =
+                            *reinterpret_cast<const uint2 *>(&Rw.SC[pl][cy * 32 + part]);
+                }
+                if (frgb) {
+                    // mb_to_rgb (export_utils.c:209-324) on the strip: 2x2 nearest chroma, integer formula :300-302
+                    const int x4 = (lane & 15) * 4;
+                    if (x4 < nb) {
+#pragma unroll 2
+                        for (int i = 0; i < 4; i++) {
+                            const int y = i * 4 + (lane >> 4);
+                            const uint32_t yw = *reinterpret_cast<const uint32_t *>(&Rw.SY[y * 64 + x4]);
+                            const uint32_t cbw = *reinterpret_cast<const uint16_t *>(&Rw.SC[0][(y >> 1) * 32 + (x4 >> 1)]);
+                            const uint32_t crw = *reinterpret_cast<const uint16_t *>(&Rw.SC[1][(y >> 1) * 32 + (x4 >> 1)]);
+                            int d0, d1, d2;   // packed 16-bit arithmetic, see recon_batch_device.h rgb4()
+                            rgb4(yw, bytes01(cbw), bytes01(crw), d0, d1, d2);
+                            // one 12-byte store per lane: the 16 lanes of a row cover its 192 bytes in one instruction
+                            typedef int v3i __attribute__((ext_vector_type(3)));
+                            typedef v3i v3i_a4 __attribute__((aligned(4)));
+                            *reinterpret_cast<v3i_a4 *>(frgb + ((size_t)(row * 16 + y) * pitch + x0 * 16 + x4) * 3) = v3i{d0, d1, d2};
+                        }
+                    }
+                }
+            }
+            WAVE_SYNC();
+        }
+    }
+}
+
+} // namespace p1
+
+size_t recon_pipe1_lds_bytes(int width_mbs, int rows)
+{
+    return sizeof(p1::P1Tables) + sizeof(p1::P1Ctl) + (size_t)width_mbs * 32 + (size_t)rows * sizeof(p1::P1Row);
+}
+
+template <int R, bool EXT>
+static hipError_t launch_pipe1_one(const ReconArgs &a, hipStream_t stream)
+{
+    const int bands = (a.height_mbs + R - 1) / R;
+    const size_t lds = recon_pipe1_lds_bytes(a.width_mbs, R);
+    hipError_t e = hipFuncSetAttribute((const void *)p1::recon_pipe1_kernel<R, EXT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((p1::recon_pipe1_kernel<R, EXT>), dim3(a.n_frames * bands), dim3(R * 3 * 64), lds, stream, a);
+    return hipGetLastError();
+}
+
+// one workgroup per (band of `rows` rows, picture); a.wide_ticket / wide_base / wide_epoch / seam set by the caller
+hipError_t launch_recon_pipe1(const ReconArgs &a, int rows, hipStream_t stream)
+{
+    if (!a.wide_ticket || !a.wide_epoch) return hipErrorInvalidValue;
+    if ((a.height_mbs + rows - 1) / rows > 1 && !a.seam) return hipErrorInvalidValue;
+    const bool ext = a.slices || a.scaling;
+    switch (rows) {
+    case 1: return ext ? launch_pipe1_one<1, true>(a, stream) : launch_pipe1_one<1, false>(a, stream);
+    case 2: return ext ? launch_pipe1_one<2, true>(a, stream) : launch_pipe1_one<2, false>(a, stream);
+    case 4: return ext ? launch_pipe1_one<4, true>(a, stream) : launch_pipe1_one<4, false>(a, stream);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+} // namespace mvhp

@@ -827,7 +827,7 @@ void Engine::launcher(int k)
                 st_.batches++;
                 st_.kernel_s += ms * 1e-3;
                 if (layout >= 0 && layout < 4) st_.launches_by_layout[layout]++;
-                else if (layout >= MVHP_LAYOUT_WIDE && layout <= MVHP_LAYOUT_PIPE) st_.launches_wide[layout - MVHP_LAYOUT_WIDE]++;
+                else if (layout >= MVHP_LAYOUT_WIDE && layout <= MVHP_LAYOUT_PIPE1) st_.launches_wide[layout - MVHP_LAYOUT_WIDE]++;
                 b->t_kernel = now_s() - t_start_;
                 cx.to_download.push_back(b->id);
             } else {

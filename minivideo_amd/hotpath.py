@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
 
-LAYOUTS = ("auto", "rows", "quad", "oct", "wide", "quad_wide", "pipe")   # MVHP_LAYOUT_*
+LAYOUTS = ("auto", "rows", "quad", "oct", "wide", "quad_wide", "pipe", "pipe1")   # MVHP_LAYOUT_*
 
 
 class MiniVideoError(RuntimeError):
@@ -253,7 +253,7 @@ class DecodeStats(C.Structure):
                 ("d2h_bytes", C.c_uint64), ("host_alloc_s", C.c_double), ("dev_alloc_s", C.c_double),
                 ("first_launch_s", C.c_double), ("first_picture_s", C.c_double), ("host_alloc_bytes", C.c_uint64),
                 ("dev_alloc_bytes", C.c_uint64), ("placed_buffers", C.c_uint32), ("reserved", C.c_uint32),
-                ("launches_wide", C.c_uint32 * 3), ("reserved2", C.c_uint32)]
+                ("launches_wide", C.c_uint32 * 4)]
 
     def as_dict(self):
         d = {}

@@ -132,7 +132,7 @@ def test_engine_reaches_the_batch_kernels(batch, forced, layout, monkeypatch):
         rc, st = eng.decode(s.h, list(range(F)), want_rgb=True, sink=sink)
     eng.close()
     assert rc == 1 and st["pictures_ok"] == F
-    by_layout = dict(zip(["auto", "rows", "quad", "oct", "wide", "quad_wide", "pipe"], list(st["launches_by_layout"]) + list(st["launches_wide"])))
+    by_layout = dict(zip(["auto", "rows", "quad", "oct", "wide", "quad_wide", "pipe", "pipe1"], list(st["launches_by_layout"]) + list(st["launches_wide"])))
     if forced or _cus() == 256:
         assert by_layout[layout] >= 1, by_layout
     for seq, (yuv, rgb) in hashes.items():

@@ -18,6 +18,8 @@ for f in glob.glob(os.path.join(out, "pass*", "**", "*counter_collection.csv"), 
             k = "recon_quad_kernel"
         elif "recon_oct" in k:
             k = "recon_oct_kernel"
+        elif "recon_pipe1" in k:
+            k = "recon_pipe1_kernel"
         elif "recon_pipe" in k:
             k = "recon_pipe_kernel"
         elif "ycbcr_to_rgb" in k:

@@ -24,7 +24,7 @@ while time.time() - t0 < budget:
     prof = ["baseline", "high"][int(rng.integers(0, 2))]
     dens = ["dense", "light"][int(rng.integers(0, 2))]
     lo = int(rng.integers(0, 40)); hi = int(rng.integers(lo, 52))
-    layout = ["rows", "quad", "oct", "wide", "quad_wide", "pipe", "wide", "quad_wide", "pipe", "auto"][int(rng.integers(0, 10))]
+    layout = ["rows", "quad", "oct", "wide", "quad_wide", "pipe", "pipe1", "wide", "quad_wide", "pipe", "pipe1", "auto"][int(rng.integers(0, 12))]
     waves = [0, 1, 2, 4, 6, 8, 12, 16][int(rng.integers(0, 8))]   # (waves per workgroup / rows per band; a form takes what it is built for)
     if rng.random() < 0.05:   # round 4: enough pictures for several groups per band and a band-major ticket order that matters
         n = int(rng.integers(14, 80))
