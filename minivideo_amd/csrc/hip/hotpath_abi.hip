@@ -212,11 +212,13 @@ MVHP_EXPORT int mvhp_set_fused_color(mvhp_ctx_t *c, int on)
 //   128 / 256 / 512 pictures, pipe 1.18 / 1.45 / 1.82, quad_wide 1.91 / 2.05 / 2.39 / 2.84 / 3.95 -- the four pictures of a
 //   wavefront run their three luma paths one after the other -- so there: wide up to 1.3 x CUs pictures, then quad_wide.
 //   Up to three pictures the quarters of a wavefront hold the SAME picture (no divergence): pipe on every profile (0.58 / 0.67 ms).
-//   pipe1 = the same three waves per row with ONE picture per wavefront (no lock step at all; profiles/r04i_crossover_*.log):
-//   Baseline 0.72 / 0.72 / 1.02 / 1.61 / 2.91 ms at 1 / 16 / 64 / 128 / 256 pictures (within 8 % of pipe up to 32 pictures, behind
-//   it beyond), High 0.64 / 0.70 / 0.98 / 1.58 / 2.88 -- against wide's 1.07 / 1.35 / 1.70 / 2.58 at 16 / 64 / 128 / 256: High
-//   batches up to 0.6 x CUs pictures of 68 rows (40 x CUs row-waves) take pipe1, and so do small batches with slices / scaling
-//   matrices, which it reconstructs as the one-picture kernel does.
+//   pipe1 = the same three waves per row with ONE picture per wavefront (no lock step at all; its Intra4x4 chain runs the two
+//   blocks of an anti-diagonal together: ten dependent steps instead of sixteen; profiles/r04i_crossover_*.log):
+//   Baseline 0.64 / 0.67 / 0.72 / 0.95 / 1.53 ms at 1 / 16 / 32 / 64 / 128 pictures (pipe: 0.58 / 0.78 / 0.81 / 0.97 / 1.26),
+//   High 0.60 / 0.67 / 0.95 / 1.55 / 2.81 at 1 / 16 / 64 / 128 / 256 -- against wide's 1.04 / 1.07 / 1.34 / 1.70 / 2.58.  So:
+//   Baseline 4 ... CUs / 4 pictures of 68 rows (17 x CUs row-waves) pipe1, then pipe; High up to 0.6 x CUs pictures (40 x CUs
+//   row-waves) pipe1, then wide; small batches with slices / scaling matrices pipe1 (it reconstructs them as the one-picture
+//   kernel does).
 static int pick_layout(const mvhp_ctx *c, const mvhp_stream_params_t *p, int n_frames)
 {
     int layout = c->layout;
@@ -234,10 +236,12 @@ static int pick_layout(const mvhp_ctx *c, const mvhp_stream_params_t *p, int n_f
         const double row_waves = (double)n_frames * (double)p->height_mbs;
         const bool may8 = (p->flags & MVHP_PARAM_MAY_HAVE_8X8) != 0;
         const bool pipe_fits = mvhp::recon_pipe_lds_bytes((int)p->width_mbs, 1) <= c->max_lds;
-        if (pipe_fits && (n_frames <= 3 || (!may8 && row_waves <= 68.0 * cus))) {
+        if (pipe_fits && !may8 && (n_frames <= 3 || (row_waves > 17.0 * cus && row_waves <= 68.0 * cus))) {
             layout = MVHP_LAYOUT_PIPE;
-        } else if (pipe1_fits && may8 && row_waves <= 40.0 * cus) {
+        } else if (pipe1_fits && row_waves <= (may8 ? 40.0 : 17.0) * cus) {
             layout = MVHP_LAYOUT_PIPE1;
+        } else if (pipe_fits && !may8 && row_waves <= 68.0 * cus) {
+            layout = MVHP_LAYOUT_PIPE;
         } else if (row_waves <= (may8 ? 90.0 : 34.0) * cus) {
             layout = MVHP_LAYOUT_WIDE;
         } else if (row_waves <= 238.0 * cus) {

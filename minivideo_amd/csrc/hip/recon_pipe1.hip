@@ -287,7 +287,11 @@ __device__ __forceinline__ Avail4 avail4(bool A, bool Bv, bool C, bool D)
     return a;
 }
 
-// Intra 4x4 macroblock: 16 dependent block steps, lanes 0..15 own one sample each.
+// Intra 4x4 macroblock: TEN dependent steps instead of sixteen -- the blocks of an anti-diagonal do not depend on each other
+// ({2,4}, {3,5}, {6,8}, {7,9}, {10,12}, {11,13}: left / up / up-left / up-right of either lie on earlier anti-diagonals, and
+// blocks 3, 11, 13 have no up-right by the rule of h264_intra_prediction.c:410-412), so lanes 0..15 predict one block of the
+// step and lanes 16..31 the other, one sample each.  (recon_rows_kernel runs the sixteen blocks one after the other on 16
+// lanes: there three more waves share the SIMD; here this chain IS the step every other row waits for.)
 // h264_intra_prediction.c:161-177, :315-483, :496-960 + transform4x4_luma (h264_transform.c:121-156).
 __device__ __forceinline__ void predict_mb_4x4(uint8_t *WT, const P1Tables &B, int lane, uint32_t m0, uint32_t m1,
                                                uint32_t m2, uint32_t m3, bool A, bool Bv, bool C, bool D, bool has_res,
@@ -298,9 +302,9 @@ __device__ __forceinline__ void predict_mb_4x4(uint8_t *WT, const P1Tables &B, i
     constexpr uint32_t REQ = (2u << 0) | (1u << 3) | (0u << 6) | (2u << 9) | (7u << 12) | (7u << 15) | (7u << 18) |
                              (2u << 21) | (1u << 24);
     const int rmask = has_res ? -1 : 0;
-    // Per-block control word, computed once by lane b for block b (16 lanes in parallel) and handed to the
-    // block steps with v_readlane: bits 0-1 left/up available, bit 2 mode is DC, bit 3 prediction allowed,
-    // bits 8.. byte offset of the block's row in the tap table.
+    // Per-block control word, computed once by lane b for block b (16 lanes in parallel) and handed to the steps with
+    // v_readlane: bits 0-1 left/up available, bit 2 mode is DC, bit 3 prediction allowed, bits 8.. byte offset of the block's
+    // row in the tap table.
     uint32_t info;
     {
         const int b = lane & 15;
@@ -312,46 +316,44 @@ __device__ __forceinline__ void predict_mb_4x4(uint8_t *WT, const P1Tables &B, i
         const uint32_t trow = (((av.upright >> b) & 1u) ? 0u : 9u) + min(mode, 8u);
         info = (avail & 3u) | ((mode == 2u) ? 4u : 0u) | (ok << 3) | ((trow * 64u) << 8);
     }
-    if (lane < 16) {
-        const int pix = (lane >> 2) * 32 + (lane & 3);   // this lane's sample inside a block, tile units
-        const int rpix = (lane >> 2) * 16 + (lane & 3);  // same in the residual array
+    if (lane < 32) {
+        const bool second = lane >= 16;                 // which block of the step this lane works on
+        const int sl = lane & 15;
+        const int pix = (sl >> 2) * 32 + (sl & 3);      // this lane's sample inside a block, tile units
+        const int rpix = (sl >> 2) * 16 + (sl & 3);     // same in the residual array
         const uint8_t *T = WT;
-        const uint8_t *tapb = reinterpret_cast<const uint8_t *>(B.tap4) + lane * 4;
-        // software pipeline: the table entry and the residual of block b+1 are fetched before block b's
-        // dependent tile reads, so only (tile read -> combine -> tile write) sits on the per-block chain
-        uint32_t inf = __builtin_amdgcn_readlane(info, 0);
-        uint32_t e_nx = *reinterpret_cast<const uint32_t *>(tapb + (inf >> 8));
-        int r_nx = (int)res[rpix];
+        const uint8_t *tapb = reinterpret_cast<const uint8_t *>(B.tap4) + sl * 4;
+        constexpr int SA[10] = {0, 1, 2, 3, 6, 7, 10, 11, 14, 15};
+        constexpr int SB[10] = {-1, -1, 4, 5, 8, 9, 12, 13, -1, -1};
 #pragma unroll
-        for (int blk = 0; blk < 16; blk++) {
-            const int xO = (((blk >> 2) & 1) << 3) | ((blk & 1) << 2);
-            const int yO = ((blk >> 3) << 3) | (((blk >> 1) & 1) << 2);
-            const int base = (yO + 1) * 32 + 16 + xO;     // tile index of the block's top-left sample
-            const uint32_t cur = inf;
-            const uint32_t e = e_nx;
-            const int r = r_nx & rmask;
-            if (blk < 15) {
-                const int nb = blk + 1;
-                const int nxO = (((nb >> 2) & 1) << 3) | ((nb & 1) << 2), nyO = ((nb >> 3) << 3) | (((nb >> 1) & 1) << 2);
-                inf = __builtin_amdgcn_readlane(info, nb);
-                e_nx = *reinterpret_cast<const uint32_t *>(tapb + (inf >> 8));
-                r_nx = (int)res[nyO * 16 + nxO + rpix];
+        for (int st = 0; st < 10; st++) {
+            constexpr auto XO = [](int b) { return (((b >> 2) & 1) << 3) | ((b & 1) << 2); };
+            constexpr auto YO = [](int b) { return ((b >> 3) << 3) | (((b >> 1) & 1) << 2); };
+            const int bA = SA[st], bB = SB[st] < 0 ? SA[st] : SB[st];
+            const bool on = !second || SB[st] >= 0;
+            const uint32_t infA = __builtin_amdgcn_readlane(info, bA), infB = __builtin_amdgcn_readlane(info, bB);
+            const uint32_t cur = second ? infB : infA;
+            const int base = second ? (YO(bB) + 1) * 32 + 16 + XO(bB) : (YO(bA) + 1) * 32 + 16 + XO(bA);   // tile index of the block's top-left sample
+            const int rbase = second ? YO(bB) * 16 + XO(bB) : YO(bA) * 16 + XO(bA);
+            if (on) {
+                const uint32_t e = *reinterpret_cast<const uint32_t *>(tapb + (cur >> 8));
+                const int r = (int)res[rbase + rpix] & rmask;
+                int pred;
+                if (cur & 4u) { // DC
+                    const int sumH = sum4(*reinterpret_cast<const uint32_t *>(&T[base - 32]));
+                    const int sumV = T[base - 1] + T[base + 31] + T[base + 63] + T[base + 95];
+                    const uint32_t lu = cur & 3u; // 3 both, 1 left only, 2 up only, 0 none
+                    const int both = (sumH + sumV + 4) >> 3, l = (sumV + 2) >> 2, u = (sumH + 2) >> 2;
+                    pred = (lu == 3u) ? both : (lu == 1u) ? l : (lu == 2u) ? u : 128;
+                } else {
+                    const int okmask = (cur & 8u) ? -1 : 0;
+                    const int a = T[base - 33 + (int)(e & 255)];
+                    const int b = T[base - 33 + (int)((e >> 8) & 255)];
+                    const int c = T[base - 33 + (int)(e >> 16)];
+                    pred = ((a + 2 * b + c + 2) >> 2) & okmask;
+                }
+                WT[base + pix] = (uint8_t)clip255(pred + r);
             }
-            int pred;
-            if (cur & 4u) { // DC
-                const int sumH = sum4(*reinterpret_cast<const uint32_t *>(&T[base - 32]));
-                const int sumV = T[base - 1] + T[base + 31] + T[base + 63] + T[base + 95];
-                const uint32_t lu = cur & 3u; // 3 both, 1 left only, 2 up only, 0 none
-                const int both = (sumH + sumV + 4) >> 3, l = (sumV + 2) >> 2, u = (sumH + 2) >> 2;
-                pred = (lu == 3u) ? both : (lu == 1u) ? l : (lu == 2u) ? u : 128;
-            } else {
-                const int okmask = (cur & 8u) ? -1 : 0;
-                const int a = T[base - 33 + (int)(e & 255)];
-                const int b = T[base - 33 + (int)((e >> 8) & 255)];
-                const int c = T[base - 33 + (int)(e >> 16)];
-                pred = ((a + 2 * b + c + 2) >> 2) & okmask;
-            }
-            WT[base + pix] = (uint8_t)clip255(pred + r);
             WAVE_SYNC();
         }
     }
