@@ -231,6 +231,9 @@ MVHP_EXPORT int  mvhp_recon_batch_host(mvhp_ctx_t *ctx, const mvhp_stream_params
                                        const void *h_packed, int n_frames,
                                        uint8_t *h_yuv, uint8_t *h_rgb);
 
+/* Test hook: the next launch of a wide kernel form hands out its work units `delta` off (see hotpath_abi.hip).  Never in products. */
+MVHP_EXPORT int  mvhp_debug_skew_next_ticket_base(mvhp_ctx_t *ctx, int delta);
+
 /* What the last reconstruction launch of this context used (speed-only choices of the launcher):
  * *layout = MVHP_LAYOUT_ROWS/QUAD/OCT, *waves = wavefronts per workgroup.  Either pointer may be NULL. */
 MVHP_EXPORT int  mvhp_last_launch_info(const mvhp_ctx_t *ctx, int *layout, int *waves);

@@ -68,6 +68,7 @@ struct mvhp_ctx {
     size_t       d_seam_bytes;
     hipEvent_t   wide_done;                 // recorded behind the last wide launch
     hipStream_t  wide_stream;               // the stream it ran on
+    int          ticket_skew_once;          // test hook (mvhp_debug_skew_next_ticket_base): added to the next wide launch's base
     // staging for the host convenience path
     void        *d_packed;
     size_t       d_packed_bytes;
@@ -357,7 +358,8 @@ static int wide_prepare(mvhp_ctx *c, mvhp::ReconArgs &a, size_t seam_bytes, uint
         c->wide_epoch = 1;
     }
     a.wide_ticket = c->d_ticket;
-    a.wide_base = c->ticket_base;
+    a.wide_base = c->ticket_base + (uint32_t)c->ticket_skew_once;
+    c->ticket_skew_once = 0;
     a.wide_epoch = c->wide_epoch;
     a.seam = (unsigned long long *)c->d_seam;
     (void)units;
@@ -526,7 +528,8 @@ MVHP_EXPORT int mvhp_recon_batch_host(mvhp_ctx_t *c, const mvhp_stream_params_t 
     HIP_TRY(hipMemcpyAsync(&err, c->d_err, sizeof(err), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (err) {
-        set_err("reconstruction kernel reported error word 0x%x (row dependency wait timed out)", err);
+        set_err("reconstruction kernel reported error word 0x%x (%s)", err,
+                (err & 2u) ? "a workgroup's ticket lay outside the launch" : "row dependency wait timed out");
         return MVHP_FAILURE;
     }
     return MVHP_SUCCESS;
@@ -541,10 +544,21 @@ MVHP_EXPORT int mvhp_sync_check(mvhp_ctx_t *c, void *stream)
     HIP_TRY(hipMemcpyAsync(&err, c->d_err, sizeof(err), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     if (err) {
-        set_err("reconstruction kernel reported error word 0x%x (row dependency wait timed out)", err);
+        set_err("reconstruction kernel reported error word 0x%x (%s)", err,
+                (err & 2u) ? "a workgroup's ticket lay outside the launch" : "row dependency wait timed out");
         hipMemset(c->d_err, 0, sizeof(uint32_t));
         return MVHP_FAILURE;
     }
+    return MVHP_SUCCESS;
+}
+
+/* Test hook (tests/test_gpu_wide.py): the next wide launch of `c` hands out its units `delta` off, i.e. one unit is never
+ * reconstructed and one ticket falls outside the launch -- what a corrupted ticket counter would look like.  The launch must END
+ * (bounded waits) with the error word set, and mvhp_sync_check() must say so. */
+MVHP_EXPORT int mvhp_debug_skew_next_ticket_base(mvhp_ctx_t *c, int delta)
+{
+    if (!c) return MVHP_FAILURE;
+    c->ticket_skew_once = delta;
     return MVHP_SUCCESS;
 }
 

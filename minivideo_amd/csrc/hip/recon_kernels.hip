@@ -562,7 +562,10 @@ __global__ __launch_bounds__(NW * 64) void recon_rows_kernel(ReconArgs a)
     // band then starts about when the band above it has got ahead, instead of holding a slot idle from the launch on
     const int band = WIDE ? unit / a.n_frames : 0;
     const int frame = WIDE ? unit - band * a.n_frames : (int)blockIdx.x;
-    if (WIDE && (unsigned)band >= (unsigned)bands) return;   // (cannot happen: the grid has n_frames * bands workgroups)
+    if (WIDE && (unsigned)unit >= (unsigned)(bands * a.n_frames)) {   // a ticket outside the launch: the host's bookkeeping of the counter is off
+        if (threadIdx.x == 0) atomicOr(a.err, 2u);
+        return;
+    }
     const int row_first = WIDE ? band * NW : 0;
     const int row_end = WIDE ? min(H, row_first + NW) : H;
     // seams: the first row of a band below the first takes its top neighbours from the seam above; the last row of a band

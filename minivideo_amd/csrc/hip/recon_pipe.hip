@@ -154,7 +154,10 @@ __global__ __launch_bounds__(PIPE_ROWS * 3 * 64) void recon_pipe_kernel(ReconArg
     const int unit = __builtin_amdgcn_readfirstlane(C.unit);
     const int band = unit / groups;
     const int grp = unit - band * groups;
-    if ((unsigned)band >= (unsigned)bands) return;   // (cannot happen: the grid has groups * bands workgroups)
+    if ((unsigned)unit >= (unsigned)(bands * groups)) {   // a ticket outside the launch: the host's bookkeeping of the counter is off
+        if (threadIdx.x == 0) atomicOr(a.err, 2u);
+        return;
+    }
     const int row = band * PIPE_ROWS + r;
     if (row >= H) return;                            // the three waves of a row beyond the picture
     PRow &R = rows[r];

@@ -592,7 +592,10 @@ __global__ __launch_bounds__(R * 3 * 64) void recon_pipe1_kernel(ReconArgs a)
     const int unit = __builtin_amdgcn_readfirstlane(C.unit);
     const int band = unit / a.n_frames;
     const int frame = unit - band * a.n_frames;
-    if ((unsigned)band >= (unsigned)bands) return;   // (cannot happen: the grid has n_frames * bands workgroups)
+    if ((unsigned)unit >= (unsigned)(bands * a.n_frames)) {   // a ticket outside the launch: the host's bookkeeping of the counter is off
+        if (threadIdx.x == 0) atomicOr(a.err, 2u);
+        return;
+    }
     const int row = band * R + r;
     if (row >= H) return;                            // the three waves of a row beyond the picture
     P1Row &Rw = rows[r];

@@ -93,7 +93,10 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_num_vgpr(100))) void
     const int unit = WIDE ? __builtin_amdgcn_readfirstlane(B.pad[0]) : 0;
     const int band = WIDE ? unit / groups : 0;                       // band-major: see recon_rows_kernel
     const int grp = WIDE ? unit - band * groups : (int)blockIdx.x;
-    if (WIDE && (unsigned)band >= (unsigned)bands) return;          // (cannot happen: the grid has groups * bands workgroups)
+    if (WIDE && (unsigned)unit >= (unsigned)(bands * groups)) {   // a ticket outside the launch: the host's bookkeeping of the counter is off
+        if (threadIdx.x == 0) atomicOr(a.err, 2u);
+        return;
+    }
     const int row_first = WIDE ? band * NW : 0;
     const int row_end = WIDE ? min(H, row_first + NW) : H;
     const bool seam_in = WIDE && wave == 0 && band > 0;             // top neighbours of this row come from the seam above

@@ -222,3 +222,32 @@ def test_hand_offs_under_uneven_load(torch_cuda, layout):
         hot.close()
     del big, big2
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("layout", WIDE)
+@pytest.mark.parametrize("delta", [-1, 1])
+def test_a_lost_unit_ends_the_launch_with_an_error(layout, delta):
+    """the waits between workgroups are bounded and any failure in a launch ends every wait: hand the units out one off (test
+    hook) -- with -1 the first band of the first picture is never reconstructed and the band below it waits for a seam that never
+    comes, with +1 a ticket falls outside the launch -- and the launch must END with the error word set, mvhp_recon_batch_host
+    must fail, and the context must reconstruct correctly again afterwards"""
+    import ctypes as C
+    import time
+    from minivideo_amd import MiniVideoError
+    hot = HotPath(0)
+    try:
+        hot.set_layout(layout)
+        params, rec = synth_packed(20, 17, 5, seed=31, profile="high", density="dense")
+        yuv_o, _ = loader.recon(params, rec, 5)
+        yuv, _ = hot.recon_host(params, rec, 5)
+        assert np.array_equal(yuv, yuv_o) and hot.last_launch()[0] == layout
+        hot._L.mvhp_debug_skew_next_ticket_base.argtypes = [C.c_void_p, C.c_int]
+        assert hot._L.mvhp_debug_skew_next_ticket_base(hot._h, delta) == 1
+        t0 = time.perf_counter()
+        with pytest.raises(MiniVideoError, match="error word"):
+            hot.recon_host(params, rec, 5)
+        assert time.perf_counter() - t0 < 30.0
+        yuv, _ = hot.recon_host(params, rec, 5)     # the hook was for one launch; the counter's bookkeeping is intact
+        assert np.array_equal(yuv, yuv_o)
+    finally:
+        hot.close()
