@@ -181,5 +181,6 @@ def synth_packed(width_mbs, height_mbs, n_frames, seed=1, profile="baseline", de
     rec[..., 12:28] = pred
     rec[..., 32:] = coef.view(np.uint8).reshape(F, N, 768)
 
-    params = StreamParams(W, H, int(cqp_offsets[0]), int(cqp_offsets[1]), 0)
+    # flags bit 0 = MVHP_PARAM_MAY_HAVE_8X8, as the front end sets it from the PPS (a hint for the choice of kernel form only)
+    params = StreamParams(W, H, int(cqp_offsets[0]), int(cqp_offsets[1]), 1 if bool(np.any(kind == KIND_I8x8)) else 0)
     return params, rec
