@@ -217,7 +217,7 @@ MVHP_EXPORT int mvhp_set_fused_color(mvhp_ctx_t *c, int on)
 //   blocks of an anti-diagonal together: ten dependent steps instead of sixteen; profiles/r04i_crossover_*.log):
 //   Baseline 0.64 / 0.67 / 0.72 / 0.95 / 1.53 ms at 1 / 16 / 32 / 64 / 128 pictures (pipe: 0.58 / 0.78 / 0.81 / 0.97 / 1.26),
 //   High 0.60 / 0.67 / 0.95 / 1.55 / 2.81 at 1 / 16 / 64 / 128 / 256 -- against wide's 1.04 / 1.07 / 1.34 / 1.70 / 2.58.  So:
-//   Baseline 4 ... CUs / 4 pictures of 68 rows (17 x CUs row-waves) pipe1, then pipe; High up to 0.6 x CUs pictures (40 x CUs
+//   Baseline 4 ... CUs / 5 pictures of 68 rows (14 x CUs row-waves) pipe1, then pipe (64 pictures: 0.92 against 0.95); High up to 0.6 x CUs pictures (40 x CUs
 //   row-waves) pipe1, then wide; small batches with slices / scaling matrices pipe1 (it reconstructs them as the one-picture
 //   kernel does).
 static int pick_layout(const mvhp_ctx *c, const mvhp_stream_params_t *p, int n_frames)
@@ -237,9 +237,9 @@ static int pick_layout(const mvhp_ctx *c, const mvhp_stream_params_t *p, int n_f
         const double row_waves = (double)n_frames * (double)p->height_mbs;
         const bool may8 = (p->flags & MVHP_PARAM_MAY_HAVE_8X8) != 0;
         const bool pipe_fits = mvhp::recon_pipe_lds_bytes((int)p->width_mbs, 1) <= c->max_lds;
-        if (pipe_fits && !may8 && (n_frames <= 3 || (row_waves > 17.0 * cus && row_waves <= 68.0 * cus))) {
+        if (pipe_fits && !may8 && (n_frames <= 3 || (row_waves > 14.0 * cus && row_waves <= 68.0 * cus))) {
             layout = MVHP_LAYOUT_PIPE;
-        } else if (pipe1_fits && row_waves <= (may8 ? 40.0 : 17.0) * cus) {
+        } else if (pipe1_fits && row_waves <= (may8 ? 40.0 : 14.0) * cus) {
             layout = MVHP_LAYOUT_PIPE1;
         } else if (pipe_fits && !may8 && row_waves <= 68.0 * cus) {
             layout = MVHP_LAYOUT_PIPE;

@@ -28,6 +28,10 @@
 #include "recon_batch_device.h"
 #include "recon_rows_device.h"
 
+#ifndef MVHP_WIDE_NAP
+#define MVHP_WIDE_NAP 1   // s_sleep units between polls of the row above in the banded instantiations (see recon_quad.hip)
+#endif
+
 namespace mvhp {
 
 // ---------------------------------------------------------------------------
@@ -377,7 +381,7 @@ __global__ __launch_bounds__(NW * 64) void recon_rows_kernel(ReconArgs a)
                 const int need = (WIDE && seam_in) ? 0 : up_base + min(mbx + 2, W);   // (seam_in: the pair's columns are in the line buffer)
                 int spins = 0;
                 while (__hip_atomic_load(&B.progress[up_wave], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < need) {
-                    __builtin_amdgcn_s_sleep(1);
+                    __builtin_amdgcn_s_sleep(WIDE ? MVHP_WIDE_NAP : 1);
                     if (++spins > (1 << 22) || __hip_atomic_load(&B.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
                         if (lane == 0) { __hip_atomic_store(&B.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); atomicOr(a.err, 1u); }
                         return;

@@ -35,6 +35,15 @@ namespace mvhp {
 #define MVHP_PRAGMA_(x) _Pragma(#x)
 #define MVHP_UNROLL(n) MVHP_PRAGMA_(unroll n)
 
+#ifndef MVHP_PIPE_NAP_F
+#define MVHP_PIPE_NAP_F 8   // s_sleep units between polls of the residual wave (it runs ahead) ...
+#endif
+#ifndef MVHP_PIPE_NAP_O
+#define MVHP_PIPE_NAP_O 3   // ... and of the chroma + output wave (it runs behind)
+#endif
+#ifndef MVHP_WIDE_NAP
+#define MVHP_WIDE_NAP 1   // s_sleep units between the luma wave's polls of the row above
+#endif
 constexpr int PIPE_ROWS_MAX = 4;    // rows per band = rows per workgroup: 1, 2 or 4 (three wavefronts each)
 #ifndef MVHP_PIPE_SLOTS
 #define MVHP_PIPE_SLOTS 4           // F -> K / O ring: F may run this many macroblocks ahead of the slower of K and O
@@ -98,11 +107,14 @@ __device__ unsigned long long g_pipe_stamps[16][2];
 #endif
 
 // spin until *ctr >= need; false = give up (error word set)
+// NAP: s_sleep units (64 clocks) between polls -- 1 on the luma chain, longer for the waves that run ahead of or behind it: a
+// polling wave spends vector-ALU issue slots (compare, branch) that the luma wave on the same SIMD wants
+template <int NAP = 1>
 __device__ __forceinline__ bool pipe_wait(const int *ctr, int need, PCtl &C, uint32_t *err, int lane)
 {
     int spins = 0;
     while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < need) {
-        __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_s_sleep(NAP);
         if (++spins > (1 << 22) || __hip_atomic_load(&C.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
             if (lane == 0) { __hip_atomic_store(&C.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); atomicOr(err, 1u); }
             return false;
@@ -214,8 +226,8 @@ __global__ __launch_bounds__(PIPE_ROWS * 3 * 64) void recon_pipe_kernel(ReconArg
             const bool any_c = __builtin_amdgcn_ballot_w64(need_c) != 0;
 
             // the slot is free once K and O have finished with macroblock mbx - NSLOT
-            if (!pipe_wait(&C.k_done[r], mbx - NSLOT + 1, C, a.err, lane)) return;
-            if (!pipe_wait(&C.o_done[r], mbx - NSLOT + 1, C, a.err, lane)) return;
+            if (!pipe_wait<MVHP_PIPE_NAP_F>(&C.k_done[r], mbx - NSLOT + 1, C, a.err, lane)) return;
+            if (!pipe_wait<MVHP_PIPE_NAP_F>(&C.o_done[r], mbx - NSLOT + 1, C, a.err, lane)) return;
 
             int r2[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // luma block j: packed int16 pairs, row-major
             int c2[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // chroma block j (j < 8)
@@ -470,7 +482,7 @@ __global__ __launch_bounds__(PIPE_ROWS * 3 * 64) void recon_pipe_kernel(ReconArg
 
             // wait for the row above: needs columns <= min(mbx+1, W-1); then fetch the top neighbours
             if (Bv) {
-                if (!seam_in && !pipe_wait(&C.k_done[r - 1], min(mbx + 2, W), C, a.err, lane)) return;
+                if (!seam_in && !pipe_wait<MVHP_WIDE_NAP>(&C.k_done[r - 1], min(mbx + 2, W), C, a.err, lane)) return;
                 // lanes 0-3 luma top, 4-5 luma up-right (when C): one dword each
                 if (j < 6 && (Cav || j < 4)) {
                     uint8_t *dst = (j < 4) ? &T[16 + j * 4] : &T[32 + (j - 4) * 4];
@@ -776,12 +788,12 @@ __global__ __launch_bounds__(PIPE_ROWS * 3 * 64) void recon_pipe_kernel(ReconArg
             }
 
             // header and chroma residuals of this macroblock; the row above's chroma of this column
-            if (!pipe_wait(&C.f_done[r], mbx + 1, C, a.err, lane)) return;
+            if (!pipe_wait<MVHP_PIPE_NAP_O>(&C.f_done[r], mbx + 1, C, a.err, lane)) return;
             const uint32_t h0 = S.hdr[0];
             const int kind = h0 & 255;
             const int cmode = (h0 >> 24) & 255;
             if (Bv) {
-                if (!seam_in && !pipe_wait(&C.c_done[r - 1], mbx + 1, C, a.err, lane)) return;
+                if (!seam_in && !pipe_wait<MVHP_PIPE_NAP_O>(&C.c_done[r - 1], mbx + 1, C, a.err, lane)) return;
                 if (j < 4) {   // lanes 0-1 Cb top, 2-3 Cr top: one dword each
                     const uint8_t *src = (j < 2) ? &line_cb[mbx * 8 + j * 4] : &line_cr[mbx * 8 + (j - 2) * 4];
                     *reinterpret_cast<uint32_t *>(&TC[j >> 1][8 + (j & 1) * 4]) = *reinterpret_cast<const uint32_t *>(src);
@@ -849,7 +861,7 @@ __global__ __launch_bounds__(PIPE_ROWS * 3 * 64) void recon_pipe_kernel(ReconArg
             WAVE_SYNC();
 
             // ---- the luma of this macroblock: park, or flush the strip ----
-            if (!pipe_wait(&C.k_done[r], mbx + 1, C, a.err, lane)) return;
+            if (!pipe_wait<MVHP_PIPE_NAP_O>(&C.k_done[r], mbx + 1, C, a.err, lane)) return;
             const int mbi = mbx & 3;
             const int m_own = j & 3, h_own = j >> 2;
             const bool flush = (mbi == 3 || mbx == W - 1);

@@ -30,6 +30,15 @@
 namespace mvhp {
 namespace p1 {
 
+#ifndef MVHP_PIPE_NAP_F
+#define MVHP_PIPE_NAP_F 8   // s_sleep units between polls of the residual wave (it runs ahead) ...
+#endif
+#ifndef MVHP_PIPE_NAP_O
+#define MVHP_PIPE_NAP_O 3   // ... and of the chroma + output wave (it runs behind)
+#endif
+#ifndef MVHP_WIDE_NAP
+#define MVHP_WIDE_NAP 1   // s_sleep units between the luma wave's polls of the row above
+#endif
 constexpr int ROWS_MAX = 4;
 constexpr int NPAIR = 3;    // F -> K / O ring, in macroblock PAIRS: F may be this many pairs ahead of the slower of K and O
 constexpr int NTILE = 3;    // K -> O ring of luma tiles
@@ -68,11 +77,14 @@ struct __attribute__((aligned(16))) P1Row {
     uint8_t  SC[2][8 * 32];        // O: output strip: 4 macroblocks of Cb / Cr
 };
 
+// NAP: s_sleep units (64 clocks) between polls -- 1 on the luma chain, longer for the waves that run ahead of or behind it: a
+// polling wave spends vector-ALU issue slots (compare, branch) that the luma wave on the same SIMD wants
+template <int NAP = 1>
 __device__ __forceinline__ bool p1_wait(const int *ctr, int need, P1Ctl &C, uint32_t *err, int lane)
 {
     int spins = 0;
     while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < need) {
-        __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_s_sleep(NAP);
         if (++spins > (1 << 22) || __hip_atomic_load(&C.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
             if (lane == 0) { __hip_atomic_store(&C.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); atomicOr(err, 1u); }
             return false;
@@ -268,8 +280,8 @@ __global__ __launch_bounds__(R * 3 * 64) void recon_pipe1_kernel(ReconArgs a)
             prefetch(mbx0 + 2, lane);
             const int slot = (mbx0 >> 1) % NPAIR;
             // the slot is free once K and O have finished with the pair NPAIR pairs back
-            if (!p1_wait(&C.k_done[r], mbx0 - 2 * NPAIR + 2, C, a.err, lane)) return;
-            if (!p1_wait(&C.o_done[r], mbx0 - 2 * NPAIR + 2, C, a.err, lane)) return;
+            if (!p1_wait<MVHP_PIPE_NAP_F>(&C.k_done[r], mbx0 - 2 * NPAIR + 2, C, a.err, lane)) return;
+            if (!p1_wait<MVHP_PIPE_NAP_F>(&C.o_done[r], mbx0 - 2 * NPAIR + 2, C, a.err, lane)) return;
             // headers: wave-uniform -> scalars (v_readlane from the header lanes)
             PairCtl pc;
 #pragma unroll
@@ -371,7 +383,7 @@ __global__ __launch_bounds__(R * 3 * 64) void recon_pipe1_kernel(ReconArgs a)
 
             // wait for the row above: needs columns <= min(mbx+1, W-1); then fetch the top neighbours
             if (BvG) {
-                if (!seam_in && !p1_wait(&C.k_done[r - 1], min(mbx + 2, W), C, a.err, lane)) return;
+                if (!seam_in && !p1_wait<MVHP_WIDE_NAP>(&C.k_done[r - 1], min(mbx + 2, W), C, a.err, lane)) return;
                 // lanes 0-3 luma top, 4-5 luma up-right (when the column exists): one dword each
                 if (lane < 6 && ((mbx < W - 1) || lane < 4))
                     *reinterpret_cast<uint32_t *>(&T[16 + lane * 4]) = *reinterpret_cast<const uint32_t *>(&line_y[mbx * 16 + lane * 4]);
@@ -460,7 +472,7 @@ __global__ __launch_bounds__(R * 3 * 64) void recon_pipe1_kernel(ReconArgs a)
             }
 
             // header and chroma residuals of this macroblock; the row above's chroma of this column
-            if (!p1_wait(&C.f_done[r], mbx + 1, C, a.err, lane)) return;
+            if (!p1_wait<MVHP_PIPE_NAP_O>(&C.f_done[r], mbx + 1, C, a.err, lane)) return;
             const uint32_t h0 = __builtin_amdgcn_readfirstlane(Rw.hdr[slot][k][0]), h1 = __builtin_amdgcn_readfirstlane(Rw.hdr[slot][k][1]);
             const uint32_t hnz = __builtin_amdgcn_readfirstlane(Rw.hdr[slot][k][2]);
             const int kind = h0 & 255;
@@ -471,7 +483,7 @@ __global__ __launch_bounds__(R * 3 * 64) void recon_pipe1_kernel(ReconArgs a)
             const bool A = (mbx > 0) && !(un & MVHP_UNAVAIL_A), D = (mbx > 0) && BvG && !(un & MVHP_UNAVAIL_D);
             const bool Bv = BvG && !(un & MVHP_UNAVAIL_B);
             if (BvG) {
-                if (!seam_in && !p1_wait(&C.c_done[r - 1], mbx + 1, C, a.err, lane)) return;
+                if (!seam_in && !p1_wait<MVHP_PIPE_NAP_O>(&C.c_done[r - 1], mbx + 1, C, a.err, lane)) return;
                 if (lane < 4) {   // lanes 0-1 Cb top, 2-3 Cr top: one dword each
                     const uint8_t *src = (lane < 2) ? &line_cb[mbx * 8 + lane * 4] : &line_cr[mbx * 8 + (lane - 2) * 4];
                     *reinterpret_cast<uint32_t *>(&Rw.TC[lane >> 1][8 + (lane & 1) * 4]) = *reinterpret_cast<const uint32_t *>(src);
@@ -491,7 +503,7 @@ __global__ __launch_bounds__(R * 3 * 64) void recon_pipe1_kernel(ReconArgs a)
             }
 
             // ---- the luma of this macroblock: into the strip ----
-            if (!p1_wait(&C.k_done[r], mbx + 1, C, a.err, lane)) return;
+            if (!p1_wait<MVHP_PIPE_NAP_O>(&C.k_done[r], mbx + 1, C, a.err, lane)) return;
             const int mbi = mbx & 3;
             {
                 const int y = lane >> 2, q = lane & 3;

@@ -36,6 +36,9 @@ namespace mvhp {
 #define MVHP_PRAGMA_(x) _Pragma(#x)
 #define MVHP_UNROLL(n) MVHP_PRAGMA_(unroll n)
 
+#ifndef MVHP_WIDE_NAP
+#define MVHP_WIDE_NAP 1   // s_sleep units between polls of the row above in the banded instantiations
+#endif
 #ifndef MVHP_CHAIN_PRIO
 #define MVHP_CHAIN_PRIO 2   // wave priority inside the Intra4x4 chain
 #endif
@@ -457,7 +460,9 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_num_vgpr(100))) void
                 const int need = (WIDE && seam_in) ? 0 : up_base + min(mbx + 2, W);   // (seam_in: the columns are in the line buffer)
                 int spins = 0;
                 while (__hip_atomic_load(&B.progress[up_wave], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < need) {
-                    __builtin_amdgcn_s_sleep(1);
+                    // (a poll costs vector-ALU issue slots -- the counter lands in a VGPR --; what a longer nap adds to a row's
+                    //  phase behind the row above it adds once per row, not per macroblock)
+                    __builtin_amdgcn_s_sleep(WIDE ? MVHP_WIDE_NAP : 1);
                     if (++spins > (1 << 22) || __hip_atomic_load(&B.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
                         if (lane == 0) { __hip_atomic_store(&B.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); atomicOr(a.err, 1u); }
                         return;

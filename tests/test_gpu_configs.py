@@ -102,7 +102,7 @@ def _tile_on_device(torch, packed, n):
 # pictures per launch -> the kernel pick_layout takes on a 256-CU MI355X for Baseline pictures (hotpath_abi.hip: four pictures over
 # 17 workgroups with three waves per row up to CUs pictures, two / one wave per row... the plain banded form up to 3.5 x CUs, then
 # one workgroup per four pictures, and per eight for whole rounds of eight per CU)
-@pytest.mark.parametrize("n,layout", [(2, "pipe"), (64, "pipe1"), (200, "pipe"), (512, "quad_wide"), (1024, "quad"), (2048, "oct"), (2080, "quad")])
+@pytest.mark.parametrize("n,layout", [(2, "pipe"), (40, "pipe1"), (64, "pipe"), (512, "quad_wide"), (1024, "quad"), (2048, "oct"), (2080, "quad")])
 def test_full_hd_batches_on_the_automatic_layout(torch_cuda, base1080, n, layout):
     torch = torch_cuda
     _, packed, p, ref = base1080

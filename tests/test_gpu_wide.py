@@ -116,7 +116,7 @@ def test_band_boundaries(layout, W, H):
 
 def test_automatic_choice_by_batch_size(torch_cuda):
     """pick_layout on a 256-CU device, Baseline: up to three pictures four pictures (the same one) per wavefront with three waves
-    per row, up to 17 x CUs row-waves (pictures x rows) one picture per wavefront with three waves per row, up to 68 x CUs four
+    per row, up to 14 x CUs row-waves (pictures x rows) one picture per wavefront with three waves per row, up to 68 x CUs four
     per wavefront again; batches that may hold Intra8x8 macroblocks: up to 40 x CUs row-waves one picture per wavefront with
     three waves per row, up to 90 x CUs one picture in bands; up to 238 x CUs four pictures in bands; then one workgroup per group"""
     torch = torch_cuda
@@ -126,8 +126,8 @@ def test_automatic_choice_by_batch_size(torch_cuda):
     try:
         hot.set_layout("auto")
         for (W, H, n, flags, want) in [(20, 17, 1, 0, "pipe"), (20, 17, 3, 1, "pipe1"), (20, 17, 4, 1, "pipe1"), (20, 17, 4, 0, "pipe1"),
-                                       (20, 17, 256, 0, "pipe1"), (20, 17, 257, 0, "pipe"),
-                                       (20, 17, 1024, 0, "pipe"), (20, 17, 1025, 0, "quad_wide"), (20, 68, 64, 0, "pipe1"), (20, 68, 65, 0, "pipe"),
+                                       (20, 17, 210, 0, "pipe1"), (20, 17, 211, 0, "pipe"),
+                                       (20, 17, 1024, 0, "pipe"), (20, 17, 1025, 0, "quad_wide"), (20, 68, 52, 0, "pipe1"), (20, 68, 53, 0, "pipe"),
                                        (20, 68, 256, 0, "pipe"),
                                        (20, 68, 257, 0, "quad_wide"), (20, 68, 150, 1, "pipe1"), (20, 68, 151, 1, "wide"),
                                        (20, 68, 338, 1, "wide"), (20, 68, 339, 1, "quad_wide"),
