@@ -238,7 +238,7 @@ def cpu_baseline(params, stream, n_distinct, rec, want_rgb, budget_s):
 
 def all_ranks_ok(ok, world, dist, dev):
     """MIN over the ranks of a per-rank verdict (a mismatch on a rank other than 0 must not pass silently)."""
-    if world <= 1:
+    if not dist.is_initialized():
         return bool(ok)
     import torch
     t = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cpu" if dist.get_backend() == "gloo" else dev)
@@ -288,20 +288,20 @@ def end_to_end(args, params, stream, n_distinct, rec, want_rgb, total, rank, wor
     # device buffers at their working size; then the timed call on the same engine -- a service that decodes stream
     # after stream is in that state
     rc0, st0 = eng.decode(h, order, want_rgb=want_rgb)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
     # three timed calls, each bracketed like the kernel leg (barrier, synchronize, MAX over the ranks); the line reports the
     # MEDIAN -- one 0.5-s call varies by several per cent from call to call on this pool -- and lists all three
     calls, rc = [], 1
     for rep in range(max(1, args.e2e_repeats)):
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
         rc_i, st_i = eng.decode(h, order, want_rgb=want_rgb, sink=sink)
         torch.cuda.synchronize(dev)
         w_i = time.perf_counter() - t0
-        if world > 1:
+        if dist.is_initialized():
             t = torch.tensor([w_i], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             w_i = float(t.item())
@@ -498,20 +498,24 @@ def main():
     rehearsal = os.environ.get("BENCH_REHEARSE_ON_ONE_GPU") == "1"
     if rehearsal:
         local_rank = 0
-    if world > 1:
+    # BENCH_RCCL_ONE_RANK=1 (tests/test_gpu_bench_rehearsal.py): an N = 1 run that makes every RCCL / gloo call of an N > 1 run
+    # (process group on the device, side group, barriers, reductions) with a world of one -- all a one-GPU box can show of them
+    use_dist = world > 1 or os.environ.get("BENCH_RCCL_ONE_RANK") == "1"
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the reconstruction hot path has no CPU fallback")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    if use_dist:
         if rehearsal:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     # a HOST-side group for waits during which another rank's work runs on this rank's device (rank 0's single-process engine
     # below): a barrier of the RCCL group is a kernel spinning on every GPU, under the collective watchdog
-    host_pg = dist.new_group(backend="gloo") if (world > 1 and not rehearsal) else None
+    host_pg = dist.new_group(backend="gloo") if (use_dist and not rehearsal) else None
 
     from minivideo_amd import HotPath
     from minivideo_amd.dist import shard
@@ -568,7 +572,7 @@ def main():
 
     # ---- the single-process multi-context leg and the cold CLI run (rank 0; the other ranks wait at the barrier below) ----
     multi = cli = None
-    if world > 1:
+    if use_dist:
         torch.cuda.synchronize()
         torch.cuda.empty_cache()           # rank 0's engine allocates on every device: leave it the room
         dist.barrier(group=host_pg)
@@ -588,7 +592,7 @@ def main():
                 cli = cli_cold(args, params, stream, n_distinct, rec)
             except Exception as ex:   # noqa: BLE001
                 cli = {"error": "%s: %s" % (type(ex).__name__, ex)}
-    if world > 1:
+    if use_dist:
         dist.barrier(group=host_pg)   # the other ranks start their kernel leg only when rank 0's engine has left their devices
 
     d_small = torch.from_numpy(rec.reshape(rec.shape[0], -1)).to(dev)
@@ -647,7 +651,7 @@ def main():
             ev[2].record(stream_t)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -667,7 +671,7 @@ def main():
     recon_name = {"rows": "recon_rows_kernel", "quad": "recon_quad_kernel", "oct": "recon_oct_kernel",
                   "wide": "recon_rows_kernel", "quad_wide": "recon_quad_kernel", "pipe": "recon_pipe_kernel", "pipe1": "recon_pipe1_kernel"}[layout_name]
 
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -785,6 +789,7 @@ def main():
             "vs_baseline": None,
             "dtype": "int32",
             "rehearsal_all_ranks_on_one_gpu": True if rehearsal else None,
+            "rccl_calls_with_one_rank": True if (use_dist and world == 1) else None,
             "data": (f"synthetic ({n_distinct} distinct {args.density} pictures of a generated "
                      f"{'CAVLC' if args.profile == 'baseline' else 'CABAC'} Annex-B stream, entropy-decoded by the host front end, "
                      if args.source == "stream" else f"synthetic ({n_distinct} distinct random {args.density} pictures, ")
@@ -844,7 +849,7 @@ def main():
                 e2e["vs_cpu_port_all_cores"] = e2e["value"] / cb["end_to_end"]["all_cores"]["value"]
         print(json.dumps(out), flush=True)
 
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     # (a leg that could not run -- its block holds "error" -- has compared nothing; one that ran and differs fails the bench)

@@ -200,26 +200,24 @@ MVHP_EXPORT int mvhp_set_fused_color(mvhp_ctx_t *c, int on)
 // Which kernel form a batch runs on: speed only, results identical.
 //   Few pictures: ONE picture (one group of four) spread over several workgroups, bands of four macroblock rows each
 //   ("wide" forms: SURVEY 7 step 5's "grid = F x PicHeightInMbs wavefronts"); many pictures: one workgroup per group of
-//   four / eight.  Measured on 1080p Baseline (tools/layout_crossover.py, profiles/r04*_crossover_*.log; ms per launch):
-//     pictures        1     16     64    128    256    512    768   1024
-//     rows          2.45   2.49   2.53   2.55   2.58   5.00     -    8.86     one workgroup per picture (rounds 1-3)
-//     quad          2.95   4.00   4.00   4.02   4.05   4.16   4.32   4.5-5.4  ... per four pictures
-//     wide          1.00   1.02   1.29   1.59   2.42   4.34     -    8.51     one picture in 17 bands
-//     quad_wide     1.06   1.38   1.46   1.69   2.01   2.85   3.91   4.96     four pictures in 17 bands
-//     pipe          0.58   0.78   0.97   1.24   1.90   3.30   4.74   6.23     ... three waves per row: residuals / luma / chroma + output
-//   so, Baseline: pipe up to CUs pictures of 68 rows, quad_wide up to 3.5 x CUs, then the round model of rounds 2-3 between
-//   the four- and the eight-picture kernel.  The thresholds scale with the rows of a picture (what fills the chip is row-waves).
-//   High profile (Intra8x8 in the mix; profiles/r04f_crossover_high*.log): wide 1.06 / 1.35 / 1.69 / 2.58 / 4.61 ms at 16 / 64 /
-//   128 / 256 / 512 pictures, pipe 1.18 / 1.45 / 1.82, quad_wide 1.91 / 2.05 / 2.39 / 2.84 / 3.95 -- the four pictures of a
-//   wavefront run their three luma paths one after the other -- so there: wide up to 1.3 x CUs pictures, then quad_wide.
-//   Up to three pictures the quarters of a wavefront hold the SAME picture (no divergence): pipe on every profile (0.58 / 0.67 ms).
-//   pipe1 = the same three waves per row with ONE picture per wavefront (no lock step at all; its Intra4x4 chain runs the two
-//   blocks of an anti-diagonal together: ten dependent steps instead of sixteen; profiles/r04i_crossover_*.log):
-//   Baseline 0.64 / 0.67 / 0.72 / 0.95 / 1.53 ms at 1 / 16 / 32 / 64 / 128 pictures (pipe: 0.58 / 0.78 / 0.81 / 0.97 / 1.26),
-//   High 0.60 / 0.67 / 0.95 / 1.55 / 2.81 at 1 / 16 / 64 / 128 / 256 -- against wide's 1.04 / 1.07 / 1.34 / 1.70 / 2.58.  So:
-//   Baseline 4 ... CUs / 5 pictures of 68 rows (14 x CUs row-waves) pipe1, then pipe (64 pictures: 0.92 against 0.95); High up to 0.6 x CUs pictures (40 x CUs
-//   row-waves) pipe1, then wide; small batches with slices / scaling matrices pipe1 (it reconstructs them as the one-picture
-//   kernel does).
+//   four / eight.  Measured on 1080p (tools/layout_crossover.py, profiles/r04l_crossover_{base,high}.log; ms per launch):
+//     Baseline      1      4     16     64    128    256    512    768   1024
+//     rows        2.45   2.47   2.49   2.53   2.55   2.58   5.00     -    8.86    one workgroup per picture (rounds 1-3)
+//     quad        2.73   3.69   3.69   3.71   3.71   3.75   3.96   4.27   4.72    ... per four pictures
+//     wide        1.00   1.00   1.01   1.21   1.50   2.34   4.16   6.06   8.00    one picture in 17 bands
+//     quad_wide   1.05   1.38   1.38   1.43   1.61   1.93   2.80   3.89   5.05    four pictures in 17 bands
+//     pipe        0.59   0.78   0.79   0.95   1.23   1.88   3.28   4.72   6.27    ... three waves per row: residuals / luma / chroma + output
+//     pipe1       0.64   0.64   0.65   0.92   1.44   2.61   5.01     -      -     one picture per wavefront, three waves per row
+//     High        1      4     16     64    128    256    512    768   1024
+//     wide        1.03   1.04   1.05   1.30   1.62   2.50   4.46   6.49   8.57
+//     quad_wide   1.18   1.91   1.91   1.99   2.20   2.61   3.70   5.12   6.47    (the four pictures of a wavefront run their
+//     pipe        0.67   1.18   1.19   1.41   1.85   2.72   4.69     -      -      three luma paths one after the other)
+//     pipe1       0.60   0.60   0.63   0.93   1.50   2.74   5.31     -      -
+//     quad        3.03   5.17   5.17   5.20   5.20   5.21   5.24   5.34   5.60
+//   Up to three Baseline pictures the quarters of a wavefront hold the SAME picture (no divergence): pipe.  pipe1 has no lock
+//   step at all and its Intra4x4 chain takes ten dependent steps instead of sixteen, but needs three resident waves per ROW.
+//   720p and 2160p: profiles/r04l_crossover_{high720,base2160,high2160,high2160b}.log.  Small batches with slices / scaling
+//   matrices: pipe1 (it reconstructs them as the one-picture kernel does), larger ones wide.
 static int pick_layout(const mvhp_ctx *c, const mvhp_stream_params_t *p, int n_frames)
 {
     int layout = c->layout;
@@ -237,15 +235,22 @@ static int pick_layout(const mvhp_ctx *c, const mvhp_stream_params_t *p, int n_f
         const double row_waves = (double)n_frames * (double)p->height_mbs;
         const bool may8 = (p->flags & MVHP_PARAM_MAY_HAVE_8X8) != 0;
         const bool pipe_fits = mvhp::recon_pipe_lds_bytes((int)p->width_mbs, 1) <= c->max_lds;
-        if (pipe_fits && !may8 && (n_frames <= 3 || (row_waves > 14.0 * cus && row_waves <= 68.0 * cus))) {
+        // round 4, after the wave priorities went in (profiles/r04l_crossover_*.log: 720p, 1080p and 2160p, both profiles): what
+        // decides between the one-picture forms is ROW-WAVES (three waves per row have to be resident), what decides between the
+        // four-picture forms is PICTURES (a round of the unbanded kernel is 4 x CUs pictures whatever their size):
+        //   Baseline  pipe (1 ... 3) | pipe1 up to 18 x CUs row-waves | pipe up to 1.25 x CUs pictures | quad_wide | quad / oct
+        //   High                       pipe1 up to 40 x CUs row-waves | wide up to 1.2 x CUs pictures  | quad_wide | quad / oct
+        // quad_wide against a first round of quad: 0.84 x 4 x CUs pictures at 120 macroblocks per row (720p: 0.80), 0.65 at 240
+        const double qw_share = fmin(0.84, fmax(0.60, 0.84 - 0.19 * ((double)p->width_mbs - 120.0) / 120.0));
+        if (pipe_fits && !may8 && n_frames <= 3) {
             layout = MVHP_LAYOUT_PIPE;
-        } else if (pipe1_fits && row_waves <= (may8 ? 40.0 : 14.0) * cus) {
+        } else if (pipe1_fits && row_waves <= (may8 ? 40.0 : 18.0) * cus) {
             layout = MVHP_LAYOUT_PIPE1;
-        } else if (pipe_fits && !may8 && row_waves <= 68.0 * cus) {
+        } else if (pipe_fits && !may8 && n_frames <= 1.25 * cus) {
             layout = MVHP_LAYOUT_PIPE;
-        } else if (row_waves <= (may8 ? 90.0 : 34.0) * cus) {
+        } else if (may8 ? (n_frames <= 1.2 * cus) : (!pipe_fits && row_waves <= 34.0 * cus)) {
             layout = MVHP_LAYOUT_WIDE;
-        } else if (row_waves <= 238.0 * cus) {
+        } else if (n_frames <= qw_share * 4.0 * cus) {
             layout = MVHP_LAYOUT_QUAD_WIDE;
         } else {
             // A launch is a number of "rounds" of one workgroup per CU (the batch kernels fill a CU with one workgroup), in

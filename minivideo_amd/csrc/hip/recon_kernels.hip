@@ -28,6 +28,13 @@
 #include "recon_batch_device.h"
 #include "recon_rows_device.h"
 
+// wave priorities inside a step: as recon_oct.hip (the chains of LDS round trips first, residuals and colour conversion fill in)
+#ifndef MVHP_ROWS_PRIO
+#define MVHP_ROWS_PRIO 1     // 0: everything at priority 0, as rounds 1-3 (K1w, 256 x 1080p: 2.64 -> 2.48 ms High, 2.52 -> 2.36 Baseline)
+#endif
+#define MVHP_RP_PRED (MVHP_ROWS_PRIO ? 1 : 0)
+#define MVHP_RP_TAIL (MVHP_ROWS_PRIO ? 2 : 0)
+#define MVHP_RP_CHAIN (MVHP_ROWS_PRIO ? 3 : 0)
 #ifndef MVHP_WIDE_NAP
 #define MVHP_WIDE_NAP 1   // s_sleep units between polls of the row above in the banded instantiations (see recon_quad.hip)
 #endif
@@ -352,6 +359,7 @@ __global__ __launch_bounds__(NW * 64) void recon_rows_kernel(ReconArgs a)
                 pc.need[k] = (rl[k] || rc[k]) && (k < npair);
             }
             pc.dc_shift_from = a.dc_shift_from;
+            if (MVHP_ROWS_PRIO) __builtin_amdgcn_s_setprio(0);
             if (pc.need[0] || pc.need[1]) residual_pair<EXT>(Wv.res, Wv.scr, B, lane_p, cA, cB, pc);
 
 #pragma unroll 1
@@ -377,6 +385,7 @@ __global__ __launch_bounds__(NW * 64) void recon_rows_kernel(ReconArgs a)
             const bool Bv = BvG && !(un & MVHP_UNAVAIL_B);
 
             // ---- wait for the row above: needs columns <= min(mbx+1, W-1) ----
+            if (MVHP_ROWS_PRIO) __builtin_amdgcn_s_setprio(MVHP_RP_PRED);
             if (BvG) {
                 const int need = (WIDE && seam_in) ? 0 : up_base + min(mbx + 2, W);   // (seam_in: the pair's columns are in the line buffer)
                 int spins = 0;
@@ -418,10 +427,14 @@ __global__ __launch_bounds__(NW * 64) void recon_rows_kernel(ReconArgs a)
             if (kind == MVHP_KIND_I16x16) {
                 predict_16x16(Wv.T, Wv.Lcol, lane, i16mode, A, Bv, D, res_luma, res);
             } else if (kind == MVHP_KIND_I4x4) {
+                if (MVHP_ROWS_PRIO) __builtin_amdgcn_s_setprio(MVHP_RP_CHAIN);
                 predict_mb_4x4(Wv, B, lane, m0, m1, m2, m3, A, Bv, C, D, res_luma, res);
+                if (MVHP_ROWS_PRIO) __builtin_amdgcn_s_setprio(MVHP_RP_PRED);
             } else {
+                if (MVHP_ROWS_PRIO) __builtin_amdgcn_s_setprio(MVHP_RP_CHAIN);
                 for (int blk = 0; blk < 4; blk++)
                     predict_8x8(Wv.T, Wv.E8, B, lane, blk, (m0 >> (blk * 8)) & 255, A, Bv, C, D, res_luma, res);
+                if (MVHP_ROWS_PRIO) __builtin_amdgcn_s_setprio(MVHP_RP_PRED);
             }
             // ---- chroma ----
             predict_chroma(Wv.TC, Wv.LcolC, lane, cmode, A, Bv, D, res_chroma, res);
@@ -441,6 +454,7 @@ __global__ __launch_bounds__(NW * 64) void recon_rows_kernel(ReconArgs a)
                 }
             }
             if (mbi == 3 || mbx == W - 1) {
+                if (MVHP_ROWS_PRIO) __builtin_amdgcn_s_setprio(0);
                 WAVE_SYNC();
                 const int x0 = mbx - mbi, nb = (mbi + 1) * 16; // strip origin (MB units), width in samples
                 {   // luma: lane -> 16 bytes of one row
@@ -478,6 +492,7 @@ __global__ __launch_bounds__(NW * 64) void recon_rows_kernel(ReconArgs a)
             }
             // ---- neighbour state for the next macroblock / next row ----
             // corners first (old top-right sample), then left columns, then the line buffer.
+            if (MVHP_ROWS_PRIO) __builtin_amdgcn_s_setprio(MVHP_RP_TAIL);
             uint32_t keep = 0, bot = 0;
             if (keep_act) keep = *keep_src;
             if (bot_act) bot = *reinterpret_cast<const uint32_t *>(bot_src);

@@ -123,8 +123,23 @@ __device__ uint32_t g_stamps[256 * 8 * 32];   // [workgroup < 256][wave < 8][bou
 #else
 #define MVHP_MARK(name)
 #endif
+// Wave priorities inside a step (round 4; `tools/ab_same_buffers.py`, profiles/r04l_ab_prio*.log).  Two waves share a SIMD's issue
+// port; when both have an instruction ready the port takes the higher priority.  The parts of a step that are chains of LDS
+// round trips (the two luma chains above all, then the neighbour fetch, chroma / Intra16x16 prediction, the hand-over of the
+// neighbour state and the publication the row below waits for) go first, the throughput parts (residuals, colour conversion)
+// fill the gaps: High 2048 x 1080p 11.24 -> 10.48 ms, Baseline 8.07 -> 7.75 ms on well-placed buffers (no change where the
+// launch waits for memory).  0 everywhere except 2 in the Intra4x4 chain was round 3's setting.
+#ifndef MVHP_PRIO_PRED
+#define MVHP_PRIO_PRED 1    // from the wait for the row above to the end of luma prediction (outside the two chains)
+#endif
+#ifndef MVHP_PRIO_TAIL
+#define MVHP_PRIO_TAIL 2    // neighbour state, publication, and on through the next record's header until the residual stage starts
+#endif
 #ifndef MVHP_CHAIN_PRIO
-#define MVHP_CHAIN_PRIO 2   // wave priority inside the Intra4x4 chain (measured: 0 -> 2 = -2 % / -6 % kernel time with / without RGB)
+#define MVHP_CHAIN_PRIO 3   // the Intra4x4 chain (measured in round 2: 0 -> 2 = -2 % / -6 % kernel time with / without RGB)
+#endif
+#ifndef MVHP_I8_PRIO
+#define MVHP_I8_PRIO 3      // the four dependent Intra8x8 blocks
 #endif
 
 // The compiler is left to the low registers (256 are available at two waves per SIMD; it needs ~190); v216-v247 are
@@ -294,6 +309,7 @@ __global__ __launch_bounds__(NW * 64) void recon_oct_kernel(ReconArgs a)
             // residuals
             // =====================================================================================
             MVHP_MARK("resid_luma");
+            __builtin_amdgcn_s_setprio(0);   // the residual stages are the throughput part of a step (priorities: see above)
             int r2[2][8];   // luma blocks 2j, 2j+1: residuals packed by row pairs (see idct4x4_ypairs)
             int c2[8];      // chroma block j
 #pragma unroll
@@ -466,6 +482,7 @@ MVHP_MARK("r_4x4_end");
             // wait for the row above: needs columns <= min(mbx+1, W-1); then fetch the top neighbours
             // =====================================================================================
             MVHP_MARK("wait_up");
+            __builtin_amdgcn_s_setprio(MVHP_PRIO_PRED);
             if (Bv) {
                 const int need = up_base + min(mbx + 2, W);
                 int spins = 0;
@@ -699,12 +716,13 @@ MVHP_MARK("p_i4_chain");
                     if (SB[t] >= 0) put(SB[t], twoB);
                     WAVE_SYNC();
                 }
-                __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_s_setprio(MVHP_PRIO_PRED);
 MVHP_MARK("p_i4_end");
             } else {
                 // Intra 8x8: h264_intra_prediction.c:1107-1353 (edge filter) + :1366-1793 + transform8x8_luma;
                 // lane j predicts row j of the block
 MVHP_MARK("p_i8");
+                __builtin_amdgcn_s_setprio(MVHP_I8_PRIO);   // the Intra8x8 blocks are a dependent chain as well
                 MVHP_UNROLL(MVHP_I8_UNROLL)
                 for (int blk = 0; blk < 4; blk++) {
                     const int bxO = (blk & 1) * 8, byO = (blk >> 1) * 8;
@@ -772,13 +790,15 @@ MVHP_MARK("p_i8");
                         const uint32_t mm = min((uint32_t)mode, 8u);
                         const bool ok = (((REQ >> (mm * 3u)) & 7u & ~avail) == 0u) && ((uint32_t)mode < 9u);   // else the prediction stays 0
                         // Intra_8x8_DC (:1435-1500) on the filtered samples: entries 2..9 (left), 11..18 (top)
-                        const int sumV = sum4(Ed[0] & 0xffff0000u) + sum4(Ed[1]) + sum4(Ed[2] & 0x0000ffffu);
-                        const int sumH = sum4(Ed[2] & 0xff000000u) + sum4(Ed[3]) + sum4(Ed[4] & 0x00ffffffu);
-                        int dcv;
-                        if (left && up) dcv = (sumH + sumV + 8) >> 4;
-                        else if (left) dcv = (sumV + 4) >> 3;
-                        else if (up) dcv = (sumH + 4) >> 3;
-                        else dcv = 128;
+                        int dcv = 128;
+                        if (__builtin_amdgcn_ballot_w64(mode == 2) != 0)   // some picture predicts DC
+                        {
+                            const int sumV = sum4(Ed[0] & 0xffff0000u) + sum4(Ed[1]) + sum4(Ed[2] & 0x0000ffffu);
+                            const int sumH = sum4(Ed[2] & 0xff000000u) + sum4(Ed[3]) + sum4(Ed[4] & 0x00ffffffu);
+                            if (left && up) dcv = (sumH + sumV + 8) >> 4;
+                            else if (left) dcv = (sumV + 4) >> 3;
+                            else if (up) dcv = (sumH + 4) >> 3;
+                        }
                         const uint2 tb = *reinterpret_cast<const uint2 *>(&B.tap8b[mm * 64 + y * 8]);
                         const uint8_t *Gb = &Q.G[0][0];
                         const uint32_t s0 = Gb[tb.x & 255u], s1 = Gb[(tb.x >> 8) & 255u], s2 = Gb[(tb.x >> 16) & 255u], s3 = Gb[tb.x >> 24];
@@ -798,6 +818,7 @@ MVHP_MARK("p_i8");
                     }
                     WAVE_SYNC();
                 }
+                __builtin_amdgcn_s_setprio(MVHP_PRIO_PRED);
 MVHP_MARK("p_i8_end");
             }
             WAVE_SYNC();
@@ -822,6 +843,7 @@ MVHP_MARK("p_i8_end");
             // strip is complete: in one store instruction lanes m = 0..3 then cover 64 contiguous bytes of a luma row
             // (32 of a chroma row), and the 192 RGB bytes of a row leave in three consecutive instructions.
             MVHP_MARK("writeout");
+            __builtin_amdgcn_s_setprio(0);
             {
                 const int mbi = mbx & 3;
                 const int m_own = j & 3, h_own = j >> 2;
@@ -956,6 +978,7 @@ MVHP_MARK("p_i8_end");
             // =====================================================================================
             MVHP_MARK("wo_end");
             MVHP_MARK("neighbours");
+            __builtin_amdgcn_s_setprio(MVHP_PRIO_TAIL);
             {
                 // left columns: lane j luma rows j, j+8 and chroma row j of both planes; corners (old top-right sample) by
                 // lanes 0-2; bottom rows -> line buffer: lanes 0-3 luma, 4-5 Cb, 6-7 Cr (one dword each)

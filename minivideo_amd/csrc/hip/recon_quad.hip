@@ -36,11 +36,26 @@ namespace mvhp {
 #define MVHP_PRAGMA_(x) _Pragma(#x)
 #define MVHP_UNROLL(n) MVHP_PRAGMA_(unroll n)
 
+#if defined(MVHP_MARKS)   // measurement builds: section markers that survive into the ISA text (tools/isa_sections.py)
+#define MVHP_MARK(name) asm volatile("; MARK " name ::: "memory")
+#else
+#define MVHP_MARK(name)
+#endif
 #ifndef MVHP_WIDE_NAP
 #define MVHP_WIDE_NAP 1   // s_sleep units between polls of the row above in the banded instantiations
 #endif
+// wave priorities inside a step: as recon_oct.hip (the chains of LDS round trips first, residuals and colour conversion fill in)
+#ifndef MVHP_PRIO_PRED
+#define MVHP_PRIO_PRED 1
+#endif
+#ifndef MVHP_PRIO_TAIL
+#define MVHP_PRIO_TAIL 2
+#endif
 #ifndef MVHP_CHAIN_PRIO
-#define MVHP_CHAIN_PRIO 2   // wave priority inside the Intra4x4 chain
+#define MVHP_CHAIN_PRIO 3   // wave priority inside the Intra4x4 chain
+#endif
+#ifndef MVHP_I8_PRIO
+#define MVHP_I8_PRIO 3
 #endif
 
 // 128 VGPRs = four waves per SIMD: two 8-wave workgroups (or four 4-wave ones) per CU; LDS allows as many.
@@ -288,12 +303,15 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_num_vgpr(100))) void
             // =====================================================================================
             // residuals (no neighbour dependency: done before waiting for the row above)
             // =====================================================================================
+            MVHP_MARK("resid_luma");
+            if (MVHP_PRIO_TAIL) __builtin_amdgcn_s_setprio(0);
             int r2[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // luma block j: packed int16 pairs, row-major
             int c2[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // chroma block j (j < 8)
             if (any_l) {
                 const int4 qt = B.q4[qpy];
                 const int shr = qt.w & 255, rnd = (qt.w >> 8) & 255, s = (qt.w >> 16) & 255, m = (qt.w >> 24) & 255;
                 if (kind == MVHP_KIND_I8x8) {
+                    MVHP_MARK("r_8x8");
                     // ---- luma 8x8 (transform_8x8_residual, h264_transform.c:1205-1383): lane j holds rows
                     //      (2i, 2i+1), i = j & 3, of 8x8 block j >> 2; rows in registers, columns after an LDS
                     //      transpose, two blocks at a time ----
@@ -355,6 +373,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_num_vgpr(100))) void
                         *reinterpret_cast<int4 *>(&Q.res[(2 * h + (j >> 3)) * 64 + (j & 7) * 8]) = o;
                     }
                 } else {
+                    MVHP_MARK("r_4x4");
                     // ---- luma 4x4 (transform_4x4_residual, h264_transform.c:1049-1191) ----
                     int d[16];
                     const int pk[8] = {cLA.x, cLA.y, cLA.z, cLA.w, cLB.x, cLB.y, cLB.z, cLB.w};   // two levels per word
@@ -404,6 +423,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_num_vgpr(100))) void
                 *reinterpret_cast<int4 *>(&Q.res[j * 16]) = make_int4(r2[0], r2[1], r2[2], r2[3]);
                 *reinterpret_cast<int4 *>(&Q.res[j * 16 + 8]) = make_int4(r2[4], r2[5], r2[6], r2[7]);
             }
+            MVHP_MARK("resid_chroma");
             if (any_c) {
                 // ---- chroma 4x4 + transform_2x2_chromadc (h264_transform.c:827-860, :924-936, :988-1005) ----
                 const int pl = (j >> 2) & 1, k = j & 3;
@@ -452,6 +472,8 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_num_vgpr(100))) void
             // =====================================================================================
             // wait for the row above: needs columns <= min(mbx+1, W-1); then fetch the top neighbours
             // =====================================================================================
+            MVHP_MARK("wait_up");
+            if (MVHP_PRIO_PRED) __builtin_amdgcn_s_setprio(MVHP_PRIO_PRED);
 #if defined(MVHP_ABL_NO_WAIT)
             if (false) {
 #else
@@ -486,6 +508,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_num_vgpr(100))) void
             // chroma prediction (h264_intra_prediction.c:2157-2564 + transform4x4_chroma): lane j < 8 predicts
             // its own 4x4 block (plane j >> 2, block j & 3)
             // =====================================================================================
+            MVHP_MARK("pred_chroma");
             if (j < 8) {
                 const int pl = j >> 2, k = j & 3;
                 const int cx = (k & 1) * 4, cy = (k >> 1) * 4;
@@ -535,6 +558,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_num_vgpr(100))) void
             // =====================================================================================
             // luma prediction
             // =====================================================================================
+            MVHP_MARK("p_i16");
             if (kind == MVHP_KIND_I16x16) {
                 // h264_intra_prediction.c:1809-2141 + transform16x16_luma; lane j predicts its own 4x4 block
                 uint32_t pw[4] = {0u, 0u, 0u, 0u};
@@ -573,6 +597,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_num_vgpr(100))) void
                 }
                 emit_block(&Q.T[(yO + 1) * 32 + 16 + xO], 32, pw, r2);
             } else if (kind == MVHP_KIND_I4x4) {
+                MVHP_MARK("p_i4");
                 // Intra 4x4: 16 dependent block steps, lane j = one sample of the block.
                 // h264_intra_prediction.c:161-177, :315-483, :496-960 + transform4x4_luma (h264_transform.c:121-156).
                 // availability per luma4x4BlkIdx (wave-uniform): deriv_neighbouringlocations, h264_spatial.c:739-786
@@ -646,10 +671,12 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_num_vgpr(100))) void
                     Q.T[base + pix] = (uint8_t)clip255(pred + r);
                     WAVE_SYNC();
                 }
-                __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_s_setprio(MVHP_PRIO_PRED);
             } else {
                 // Intra 8x8: h264_intra_prediction.c:1107-1353 (edge filter) + :1366-1793 + transform8x8_luma;
                 // lane j predicts samples (4*(j&1) .. +3, j>>1) of the block
+                MVHP_MARK("p_i8");
+                if (MVHP_I8_PRIO) __builtin_amdgcn_s_setprio(MVHP_I8_PRIO);
                 MVHP_UNROLL(MVHP_I8_UNROLL)
                 for (int blk = 0; blk < 4; blk++) {
                     const int bxO = (blk & 1) * 8, byO = (blk >> 1) * 8;
@@ -724,8 +751,10 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_num_vgpr(100))) void
                     }
                     WAVE_SYNC();
                 }
+                if (MVHP_I8_PRIO) __builtin_amdgcn_s_setprio(MVHP_PRIO_PRED);
             }
 
+            MVHP_MARK("pred_end");
             WAVE_SYNC();
             // I_PCM (8.3.5; only MVHP_STREAM_SPEC streams carry it): the samples as they are, over whatever
             // the prediction paths above made of such a record.  Record layout (minivideo_hotpath.h): the owner of luma block
@@ -747,6 +776,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_num_vgpr(100))) void
             // =====================================================================================
             // write-out (mb_to_rgb, export_utils.c:209-324, fused): park, or flush the 4-macroblock strip
             // =====================================================================================
+            MVHP_MARK("writeout");
             {
                 const int mbi = mbx & 3;
                 const int m_own = j & 3, h_own = j >> 2;
@@ -757,6 +787,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_num_vgpr(100))) void
                     L2 = *reinterpret_cast<const v4i *>(t0 + 2 * 32);   L3 = *reinterpret_cast<const v4i *>(t0 + 3 * 32);
                 }
                 if (mbi == 3 || mbx == W - 1) {
+                    if (MVHP_PRIO_PRED) __builtin_amdgcn_s_setprio(0);   // the flush (colour conversion) is throughput work; taking / parking is not
                     uint32_t qmb_v = qmb;
                     asm volatile("" : "+v"(qmb_v));
                     // chroma rows 2h, 2h + 1 of the lane's macroblock: parked ones from the strip, the current one from the tile
@@ -843,6 +874,8 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_num_vgpr(100))) void
             // =====================================================================================
             // neighbour state for the next macroblock / next row, then publish
             // =====================================================================================
+            MVHP_MARK("neighbours");
+            if (MVHP_PRIO_TAIL) __builtin_amdgcn_s_setprio(MVHP_PRIO_TAIL);
             {
                 // corners (old top-right sample) by lanes 0-2, left columns: lane j luma row j; lane j chroma
                 // row j & 7 of plane j >> 3; bottom rows -> line buffer by lanes 0-7 (one dword each)

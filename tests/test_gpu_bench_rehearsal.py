@@ -53,3 +53,21 @@ def test_two_ranks_one_line(mode):
     multi = d["engine_multi_context"]
     assert "error" not in multi, multi
     assert multi["contexts"] == 2 and multi["bit_exact_vs_oracle"] is True and multi["rehearsal_contexts_share_devices"] is True
+
+
+def test_every_rccl_call_of_an_n_gpu_run_with_a_world_of_one():
+    """The N > 1 run initialises RCCL on the rank's device (`init_process_group("nccl", device_id=...)`), opens a gloo side group,
+    and uses barriers and MAX / MIN reductions of device tensors.  No second GPU exists on the test box, so this is the most of
+    that path it can run: the same calls, in the same order, with world_size = 1 (BENCH_RCCL_ONE_RANK=1) -- RCCL loads, the
+    communicator comes up on the device, the collectives return, the line is printed and the group is destroyed."""
+    env = dict(os.environ, BENCH_RCCL_ONE_RANK="1", HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533",
+               RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+           "--placement-trials", "0", "--cli-pictures", "0", "--e2e-repeats", "1", "--frames", "48", "--e2e-pictures", "48"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["rccl_calls_with_one_rank"] is True and d["rehearsal_all_ranks_on_one_gpu"] is None
+    assert d["config"]["bit_exact_vs_oracle"] is True and d["end_to_end"]["bit_exact_vs_oracle"] is True and d["value"] > 0

@@ -102,12 +102,12 @@ def test_engine_wanted_caps_entropy_work():
         assert got[i][0] == k and np.array_equal(got[i][3], loader.recon(p, packed[k], 1)[0])
 
 
-@pytest.mark.parametrize("batch,forced,layout", [(1024, None, "pipe"), (2048, "wide", "wide"), (2048, "quad_wide", "quad_wide"),
+@pytest.mark.parametrize("batch,forced,layout", [(1024, None, "pipe1"), (2048, "wide", "wide"), (2048, "quad_wide", "quad_wide"),
                                                  (1024, "quad", "quad"), (2048, "oct", "oct")])
 def test_engine_reaches_the_batch_kernels(batch, forced, layout, monkeypatch):
-    """what pick_layout (hotpath_abi.hip) makes of the engine's large batches of SMALL pictures (6 rows: 1024 of them are 6144
-    row-waves -> four pictures in bands, three waves per row), and every other form forced through the environment (the
-    one-workgroup-per-group kernels are the automatic choice from ~900 full-HD pictures per launch on)"""
+    """what pick_layout (hotpath_abi.hip) makes of the engine's batches of SMALL pictures (6 rows: the ramp's batches of 16 ... 512
+    are at most 3072 row-waves -> one picture per wavefront, three waves per row), and every other form forced through the
+    environment (the one-workgroup-per-group kernels are the automatic choice from ~860 pictures per launch on)"""
     W, H, D = 12, 6, 32
     F = 2080
     if forced:

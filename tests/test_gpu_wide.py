@@ -115,10 +115,11 @@ def test_band_boundaries(layout, W, H):
 
 
 def test_automatic_choice_by_batch_size(torch_cuda):
-    """pick_layout on a 256-CU device, Baseline: up to three pictures four pictures (the same one) per wavefront with three waves
-    per row, up to 14 x CUs row-waves (pictures x rows) one picture per wavefront with three waves per row, up to 68 x CUs four
-    per wavefront again; batches that may hold Intra8x8 macroblocks: up to 40 x CUs row-waves one picture per wavefront with
-    three waves per row, up to 90 x CUs one picture in bands; up to 238 x CUs four pictures in bands; then one workgroup per group"""
+    """pick_layout on a 256-CU device.  Baseline: up to three pictures four pictures (the same one) per wavefront with three waves
+    per row; up to 18 x CUs row-waves (pictures x rows) one picture per wavefront with three waves per row; up to 1.25 x CUs
+    PICTURES four per wavefront again; up to 0.84 x 4 x CUs pictures four pictures in bands; then one workgroup per group.
+    Batches that may hold Intra8x8 macroblocks: up to 40 x CUs row-waves one picture per wavefront with three waves per row, up
+    to 1.2 x CUs pictures one picture in bands, then as Baseline."""
     torch = torch_cuda
     if torch.cuda.get_device_properties(0).multi_processor_count != 256:
         pytest.skip("thresholds are stated for 256 CUs")
@@ -126,12 +127,12 @@ def test_automatic_choice_by_batch_size(torch_cuda):
     try:
         hot.set_layout("auto")
         for (W, H, n, flags, want) in [(20, 17, 1, 0, "pipe"), (20, 17, 3, 1, "pipe1"), (20, 17, 4, 1, "pipe1"), (20, 17, 4, 0, "pipe1"),
-                                       (20, 17, 210, 0, "pipe1"), (20, 17, 211, 0, "pipe"),
-                                       (20, 17, 1024, 0, "pipe"), (20, 17, 1025, 0, "quad_wide"), (20, 68, 52, 0, "pipe1"), (20, 68, 53, 0, "pipe"),
-                                       (20, 68, 256, 0, "pipe"),
-                                       (20, 68, 257, 0, "quad_wide"), (20, 68, 150, 1, "pipe1"), (20, 68, 151, 1, "wide"),
-                                       (20, 68, 338, 1, "wide"), (20, 68, 339, 1, "quad_wide"),
-                                       (6, 68, 896, 0, "quad_wide"), (6, 68, 897, 0, "quad")]:
+                                       (20, 17, 271, 0, "pipe1"), (20, 17, 272, 0, "pipe"),
+                                       (20, 17, 320, 0, "pipe"), (20, 17, 321, 0, "quad_wide"), (20, 68, 67, 0, "pipe1"), (20, 68, 68, 0, "pipe"),
+                                       (20, 68, 320, 0, "pipe"),
+                                       (20, 68, 321, 0, "quad_wide"), (20, 68, 150, 1, "pipe1"), (20, 68, 151, 1, "wide"),
+                                       (20, 68, 307, 1, "wide"), (20, 68, 308, 1, "quad_wide"),
+                                       (6, 68, 860, 0, "quad_wide"), (6, 68, 861, 0, "quad")]:
             params, rec = synth_packed(W, H, 4, seed=7, profile="baseline", density="light")
             params.flags = flags   # bit 0: MVHP_PARAM_MAY_HAVE_8X8 (a hint for this choice only)
             d_packed = _tile(torch, rec, n)

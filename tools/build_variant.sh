@@ -25,4 +25,5 @@ for s in $R/minivideo_amd/csrc/hip/*.hip; do
 done
 HOST=$(ls $R/minivideo_amd/build/*.o | grep -v "\.hip\.o")
 /opt/rocm/bin/hipcc --offload-arch=gfx950 --hip-link -shared -fPIC -pthread -o $O/libminivideo.so $HOST $OBJS
+[ -n "$MVHP_KEEP_TEMPS" ] || rm -rf $O/temps_* $O/*.o   # (65 MB per variant: the snapshot sent to the GPU box is capped)
 echo built $O/libminivideo.so
