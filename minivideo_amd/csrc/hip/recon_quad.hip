@@ -711,32 +711,31 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_num_vgpr(100))) void
                     {
                         const int y = j >> 1, x0 = (j & 1) * 4;
                         uint32_t pwv = 0;
-                        if (mode == 2) {
-                            const uint32_t *E = reinterpret_cast<const uint32_t *>(Q.E8);
-                            const uint32_t w0 = E[0], w1 = E[1], w2 = E[2], w3 = E[3], w4 = E[4];
-                            const int sumV = sum4(w0 & 0xffff0000u) + sum4(w1) + sum4(w2 & 0x0000ffffu);       // E8[2..9]
-                            const int sumH = sum4(w2 & 0xff000000u) + sum4(w3) + sum4(w4 & 0x00ffffffu);       // E8[11..18]
-                            int v;
-                            if (left && up) v = (sumH + sumV + 8) >> 4;
-                            else if (left) v = (sumV + 4) >> 3;
-                            else if (up) v = (sumH + 4) >> 3;
-                            else v = 128;
-                            pwv = (uint32_t)v * 0x01010101u;
-                        } else {
-                            bool ok;
-                            switch (mode) {
-                            case 0: case 3: case 7: ok = up; break;
-                            case 1: case 8: ok = left; break;
-                            default: ok = left && up && upleft; break;
-                            }
-                            if (ok && mode < 9) {
-                                const uint4 e4 = *reinterpret_cast<const uint4 *>(&B.tap8[mode * 64 + y * 8 + x0]);
-                                const uint32_t ee[4] = {e4.x, e4.y, e4.z, e4.w};
+                        {   // one path for the four pictures (round 4): taps for every lane, DC only when some picture wants it
+                            const uint32_t mm = min((uint32_t)mode, 8u);
+                            constexpr uint32_t REQ8 = (2u << 0) | (1u << 3) | (0u << 6) | (2u << 9) | (7u << 12) | (7u << 15) | (7u << 18) |
+                                                      (2u << 21) | (1u << 24);
+                            const uint32_t avail = (left ? 1u : 0u) | (up ? 2u : 0u) | (upleft ? 4u : 0u);
+                            const bool ok = (((REQ8 >> (mm * 3u)) & 7u & ~avail) == 0u) && ((uint32_t)mode < 9u);
+                            const uint4 e4 = *reinterpret_cast<const uint4 *>(&B.tap8[mm * 64 + y * 8 + x0]);
+                            const uint32_t ee[4] = {e4.x, e4.y, e4.z, e4.w};
 #pragma unroll
-                                for (int x = 0; x < 4; x++) {
-                                    const int v0 = Q.E8[ee[x] & 255], v1 = Q.E8[(ee[x] >> 8) & 255], v2 = Q.E8[ee[x] >> 16];
-                                    pwv |= (uint32_t)((v0 + 2 * v1 + v2 + 2) >> 2) << (8 * x);
-                                }
+                            for (int x = 0; x < 4; x++) {
+                                const int v0 = Q.E8[ee[x] & 255], v1 = Q.E8[(ee[x] >> 8) & 255], v2 = Q.E8[ee[x] >> 16];
+                                pwv |= (uint32_t)((v0 + 2 * v1 + v2 + 2) >> 2) << (8 * x);
+                            }
+                            pwv &= ok ? 0xffffffffu : 0u;
+                            if (__builtin_amdgcn_ballot_w64(mode == 2) != 0) {
+                                const uint32_t *E = reinterpret_cast<const uint32_t *>(Q.E8);
+                                const uint32_t w0 = E[0], w1 = E[1], w2 = E[2], w3 = E[3], w4 = E[4];
+                                const int sumV = sum4(w0 & 0xffff0000u) + sum4(w1) + sum4(w2 & 0x0000ffffu);       // E8[2..9]
+                                const int sumH = sum4(w2 & 0xff000000u) + sum4(w3) + sum4(w4 & 0x00ffffffu);       // E8[11..18]
+                                int v;
+                                if (left && up) v = (sumH + sumV + 8) >> 4;
+                                else if (left) v = (sumV + 4) >> 3;
+                                else if (up) v = (sumH + 4) >> 3;
+                                else v = 128;
+                                pwv = (mode == 2) ? (uint32_t)v * 0x01010101u : pwv;
                             }
                         }
                         int rr[4] = {0, 0, 0, 0};
