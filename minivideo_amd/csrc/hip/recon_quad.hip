@@ -677,6 +677,21 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_num_vgpr(100))) void
                 // lane j predicts samples (4*(j&1) .. +3, j>>1) of the block
                 MVHP_MARK("p_i8");
                 if (MVHP_I8_PRIO) __builtin_amdgcn_s_setprio(MVHP_I8_PRIO);
+                // The lane's two entries of the unified edge (recon_device.h mode_entry: 0-1 left[7] replicated, 2-9 left[7..0],
+                // 10 corner, 11-26 top[0..15], 27 replicated) and where their three taps lie RELATIVE to the block's top row in the
+                // tile: that does not depend on the block, so it is worked out once per macroblock; a block only picks between the
+                // neighbour and the sample itself where a side is missing (scalar conditions) and clamps the taps beyond top[7]
+                // when there is no up-right block (:1230-1236).
+                int e_of[2], o_e[2], o_lo[2], o_hi[2];
+#pragma unroll
+                for (int half = 0; half < 2; half++) {
+                    const int e = min(max(j + 16 * half, 2), 26);
+                    const int lo = max(e - 1, 2), hi = min(e + 1, 26);
+                    e_of[half] = e;
+                    o_e[half] = (e >= 10) ? e - 11 : 31 + (9 - e) * 32;
+                    o_lo[half] = (lo >= 10) ? lo - 11 : 31 + (9 - lo) * 32;
+                    o_hi[half] = (hi >= 10) ? hi - 11 : 31 + (9 - hi) * 32;
+                }
                 MVHP_UNROLL(MVHP_I8_UNROLL)
                 for (int blk = 0; blk < 4; blk++) {
                     const int bxO = (blk & 1) * 8, byO = (blk >> 1) * 8;
@@ -686,26 +701,19 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_num_vgpr(100))) void
                     const bool upleft = (bxO > 0) ? ((byO > 0) || Bv) : ((byO > 0) ? A : D);
                     const bool upright = (blk == 0) ? Bv : (blk == 1) ? C : (blk == 2);
                     const uint8_t *Trow = &Q.T[byO * 32 + 16 + bxO];
-                    const uint8_t *Tcol = &Q.T[(byO + 1) * 32 + 15 + bxO];
 #pragma unroll
                     for (int half = 0; half < 2; half++) {
-                        const int el = j + 16 * half;
-                        if (el < 28) {
-                            // raw edge sample for EE8 index e: e<=9: left[9-e] (clamped), 10: corner, >=11: top[e-11]
-                            const int e = min(max(el, 2), 26);
-                            const int maxi = upright ? 15 : 7;
-                            int lo = e - 1, hi = e + 1;
-                            if (e == 2 || (e == 11 && !upleft) || (e == 10 && !left)) lo = e;
-                            if (e == 26 || (e == 9 && !upleft) || (e == 10 && !up)) hi = e;
-                            int v[3];
-                            const int idxs[3] = {lo, e, hi};
-#pragma unroll
-                            for (int t = 0; t < 3; t++) {
-                                const int idx = idxs[t];
-                                v[t] = (idx >= 10) ? (int)Trow[min(idx - 11, maxi)] : (int)Tcol[(9 - idx) * 32];
-                            }
-                            Q.E8[el] = (uint8_t)((v[0] + 2 * v[1] + v[2] + 2) >> 2);
+                        const int e = e_of[half];
+                        int a_lo = (((e == 11) && !upleft) || ((e == 10) && !left)) ? o_e[half] : o_lo[half];
+                        int a_hi = (((e == 9) && !upleft) || ((e == 10) && !up)) ? o_e[half] : o_hi[half];
+                        int a_e = o_e[half];
+                        if (!upright) {
+                            a_lo = (e > 19) ? 7 : a_lo;
+                            a_e = (e > 18) ? 7 : a_e;
+                            a_hi = (e > 17) ? 7 : a_hi;
                         }
+                        const int v0 = Trow[a_lo], v1 = Trow[a_e], v2 = Trow[a_hi];
+                        if (half == 0 || j < 12) Q.E8[j + 16 * half] = (uint8_t)((v0 + 2 * v1 + v2 + 2) >> 2);
                     }
                     WAVE_SYNC();
                     {
