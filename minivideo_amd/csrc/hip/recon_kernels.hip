@@ -432,8 +432,9 @@ __global__ __launch_bounds__(NW * 64) void recon_rows_kernel(ReconArgs a)
                 if (MVHP_ROWS_PRIO) __builtin_amdgcn_s_setprio(MVHP_RP_PRED);
             } else {
                 if (MVHP_ROWS_PRIO) __builtin_amdgcn_s_setprio(MVHP_RP_CHAIN);
+                const Edge8 g8 = edge8_of(lane);
                 for (int blk = 0; blk < 4; blk++)
-                    predict_8x8(Wv.T, Wv.E8, B, lane, blk, (m0 >> (blk * 8)) & 255, A, Bv, C, D, res_luma, res);
+                    predict_8x8(Wv.T, Wv.E8, B, lane, g8, blk, (m0 >> (blk * 8)) & 255, A, Bv, C, D, res_luma, res);
                 if (MVHP_ROWS_PRIO) __builtin_amdgcn_s_setprio(MVHP_RP_PRED);
             }
             // ---- chroma ----

@@ -412,8 +412,9 @@ __global__ __launch_bounds__(R * 3 * 64) void recon_pipe1_kernel(ReconArgs a)
             } else if (kind == MVHP_KIND_I4x4) {
                 predict_mb_4x4(T, B, lane, m0, m1, m2, m3, A, Bv, Cav, D, res_luma, res);
             } else {
+                const Edge8 g8 = edge8_of(lane);
                 for (int blk = 0; blk < 4; blk++)
-                    predict_8x8(T, Rw.E8, B, lane, blk, (m0 >> (blk * 8)) & 255, A, Bv, Cav, D, res_luma, res);
+                    predict_8x8(T, Rw.E8, B, lane, g8, blk, (m0 >> (blk * 8)) & 255, A, Bv, Cav, D, res_luma, res);
             }
 
             // ---- luma neighbour state for the next macroblock (built in the NEXT tile) / the next row, then publish ----

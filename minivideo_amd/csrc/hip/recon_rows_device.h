@@ -201,8 +201,25 @@ __device__ __forceinline__ Avail4 avail4(bool A, bool Bv, bool C, bool D)
 
 // Intra 8x8 block: edge filtering by lanes 0..27, prediction by all 64 lanes.
 // h264_intra_prediction.c:1107-1353 + :1366-1793 + transform8x8_luma.
+// A lane's entry of the unified Intra8x8 edge (recon_device.h mode_entry: 0-1 left[7] replicated, 2-9 left[7..0], 10 corner, 11-26
+// top[0..15], 27 replicated) and where its three taps lie RELATIVE to the block's top row in the tile: the same for the four blocks
+// of a macroblock, so it is worked out once per macroblock (round 4; as recon_quad.hip).
+struct Edge8 {
+    int e, o_e, o_lo, o_hi;
+};
+__device__ __forceinline__ Edge8 edge8_of(int lane)
+{
+    Edge8 g;
+    g.e = min(max(lane, 2), 26);
+    const int lo = max(g.e - 1, 2), hi = min(g.e + 1, 26);
+    g.o_e = (g.e >= 10) ? g.e - 11 : 31 + (9 - g.e) * 32;
+    g.o_lo = (lo >= 10) ? lo - 11 : 31 + (9 - lo) * 32;
+    g.o_hi = (hi >= 10) ? hi - 11 : 31 + (9 - hi) * 32;
+    return g;
+}
+
 template <class Tables>
-__device__ __forceinline__ void predict_8x8(uint8_t *WT, uint8_t *WE8, const Tables &B, int lane, int blk, int mode,
+__device__ __forceinline__ void predict_8x8(uint8_t *WT, uint8_t *WE8, const Tables &B, int lane, const Edge8 &g, int blk, int mode,
                                             bool A, bool Bv, bool C, bool D, bool has_res, const int16_t *res)
 {
     const int xO = (blk & 1) * 8, yO = (blk >> 1) * 8;
@@ -211,25 +228,20 @@ __device__ __forceinline__ void predict_8x8(uint8_t *WT, uint8_t *WE8, const Tab
     const bool upleft = (xO > 0) ? ((yO > 0) || Bv) : ((yO > 0) ? A : D);
     const bool upright = (blk == 0) ? Bv : (blk == 1) ? C : (blk == 2);
     const uint8_t *Trow = &WT[yO * 32 + 16 + xO];
-    const uint8_t *Tcol = &WT[(yO + 1) * 32 + 15 + xO];
     if (lane < 28) {
-        // raw edge sample for EE8 index e: e<=9: left[9-e] (clamped), 10: corner, >=11: top[e-11]
-        const int e = min(max(lane, 2), 26);
-        const int maxi = upright ? 15 : 7;
-        int lo = e - 1, hi = e + 1;
-        if (e == 2 || (e == 11 && !upleft) || (e == 10 && !left)) lo = e;
-        if (e == 26 || (e == 9 && !upleft) || (e == 10 && !up)) hi = e;
-        int v[3];
-        const int idxs[3] = {lo, e, hi};
-#pragma unroll
-        for (int q = 0; q < 3; q++) {
-            const int idx = idxs[q];
-            int a;
-            if (idx >= 10) a = (int)Trow[min(idx - 11, maxi)];
-            else a = (int)Tcol[(9 - idx) * 32];
-            v[q] = a;
+        // a missing side: the neighbour is the sample itself (h264_intra_prediction.c:1295-1353); no up-right block: the taps
+        // beyond top[7] read top[7] (:1230-1236)
+        const int e = g.e;
+        int a_lo = (((e == 11) && !upleft) || ((e == 10) && !left)) ? g.o_e : g.o_lo;
+        int a_hi = (((e == 9) && !upleft) || ((e == 10) && !up)) ? g.o_e : g.o_hi;
+        int a_e = g.o_e;
+        if (!upright) {
+            a_lo = (e > 19) ? 7 : a_lo;
+            a_e = (e > 18) ? 7 : a_e;
+            a_hi = (e > 17) ? 7 : a_hi;
         }
-        WE8[lane] = (uint8_t)((v[0] + 2 * v[1] + v[2] + 2) >> 2);
+        const int v0 = Trow[a_lo], v1 = Trow[a_e], v2 = Trow[a_hi];
+        WE8[lane] = (uint8_t)((v0 + 2 * v1 + v2 + 2) >> 2);
     }
     WAVE_SYNC();
     {
