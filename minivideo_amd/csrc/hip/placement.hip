@@ -1,12 +1,12 @@
 // placement.hip -- where in device memory the buffers of a batch should live (MI355X).
 //
-// Measured on MI355X (NPS1 / SPX; tools/placement_map.py, profiles/r02d_placement_map.log): device memory comes in regions
+// Measured on MI355X (NPS1 / SPX; tools/placement/placement_map.py, profiles/r02d_placement_map.log): device memory comes in regions
 // of tens of GB that alternate between two halves of the memory system, and a kernel whose concurrent streams all live in
 // one half sees half the bandwidth -- the 1080p Baseline launch takes 9.6-10.0 ms with planes and RGB in regions of the
 // same kind and 8.2-8.4 ms with them in different kinds, whatever the offsets inside a region.  hipMalloc hands out one
 // region after the other, so which case a caller gets is chance.  This file (a) tells the groups of two addresses apart with
 // a timing probe and (b) places the buffers of a batch inside one large allocation so that each stream has a group of its own
-// (tools/placement_predict.py: planes, RGB and records in three different groups = the fastest case, every time).
+// (tools/placement/placement_predict.py: planes, RGB and records in three different groups = the fastest case, every time).
 // (An earlier attempt built buffers from 1-GB chunks of HIP virtual memory management taken in turn from every group:
 // commit 2951923; separately created chunks did not classify reliably, see DESIGN.md.)
 #include <hip/hip_runtime.h>

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """A/B timing of builds of libminivideo.so (tools/build_variant.sh) inside ONE process on the SAME device buffers.
 
-Why: the time of the 1080p Baseline launch depends on where its buffers were placed (tools/alloc_variance.py: 9.1 ... 12.4 ms
+Why: the time of the 1080p Baseline launch depends on where its buffers were placed (tools/placement/alloc_variance.py: 9.1 ... 12.4 ms
 for one binary in one process), so timings from different processes, let alone boxes, do not compare builds.  Here every
 build is loaded side by side (RTLD_LOCAL), the buffers are re-allocated `--trials` times, and every build runs on each set.
 usage (GPU box, repo root): python tools/ab_same_buffers.py product=minivideo_amd/libminivideo.so x=abl_tmp/x/libminivideo.so

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Measurement: does the Baseline kernel's time depend on WHERE its buffers were allocated?  One process, the same
 records, the output (and then the input) buffers re-allocated several times with the earlier ones kept alive, 10 launches each.
-usage (GPU box, repo root): python tools/alloc_variance.py [--profile baseline|high] [--frames 2048]"""
+usage (GPU box, repo root): python tools/placement/alloc_variance.py [--profile baseline|high] [--frames 2048]"""
 import argparse
 import os
 import sys
@@ -10,7 +10,7 @@ import time
 import numpy as np
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from minivideo_amd import HotPath
 from minivideo_amd.synth import synth_packed
 

@@ -1,7 +1,7 @@
 #!/bin/bash
-# tools/alloc_variance.py under rocprofv3 --pmc, one counter group per pass: per-dispatch counters next to the script's own
+# tools/placement/alloc_variance.py under rocprofv3 --pmc, one counter group per pass: per-dispatch counters next to the script's own
 # per-allocation times (1 warm + 2 timed launches per line of the log, in dispatch order).
-# usage (GPU box, repo root): bash tools/alloc_variance_pmc.sh <tag> "<counters of pass 1>" ["<counters of pass 2>" ...]
+# usage (GPU box, repo root): bash tools/placement/alloc_variance_pmc.sh <tag> "<counters of pass 1>" ["<counters of pass 2>" ...]
 TAG=$1; shift
 R=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$R/gpurun_out/av_$TAG
@@ -11,7 +11,7 @@ cd /tmp
 i=0
 for grp in "$@"; do
   i=$((i+1))
-  timeout -k 10 240 rocprofv3 --pmc $grp --output-format csv -d $OUT/pass$i -- python3 $R/tools/alloc_variance.py --launches 2 --warm 1 --trials 8 > $OUT/pass$i.log 2>&1 || { echo "pass $i failed or timed out"; exit 1; }
+  timeout -k 10 240 rocprofv3 --pmc $grp --output-format csv -d $OUT/pass$i -- python3 $R/tools/placement/alloc_variance.py --launches 2 --warm 1 --trials 8 > $OUT/pass$i.log 2>&1 || { echo "pass $i failed or timed out"; exit 1; }
   python3 - $OUT/pass$i $OUT/pass$i.log <<'PY'
 import csv, glob, os, sys
 from collections import defaultdict

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Measurement: the launch on buffers from mvhp_placed_alloc() against ordinary allocations, one process.
-usage (GPU box, repo root): python tools/placed_check.py [--profile baseline|high] [--mbs 120x68] [--frames 2048]"""
+usage (GPU box, repo root): python tools/placement/placed_check.py [--profile baseline|high] [--mbs 120x68] [--frames 2048]"""
 import argparse
 import ctypes as C
 import os
@@ -9,7 +9,7 @@ import time
 
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from minivideo_amd import HotPath
 from minivideo_amd.hotpath import lib
 from minivideo_amd.synth import synth_packed

@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
 """Measurement: the Baseline launch as a function of the ABSOLUTE position of its buffers inside one 230 GB allocation.
-usage (GPU box, repo root): python tools/placement_map.py"""
+usage (GPU box, repo root): python tools/placement/placement_map.py"""
 import os
 import sys
 
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from minivideo_amd import HotPath
 from minivideo_amd.synth import synth_packed
 

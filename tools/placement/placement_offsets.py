@@ -1,13 +1,13 @@
 #!/usr/bin/env python3
 """Measurement: the Baseline launch with its three buffers at controlled offsets inside ONE large allocation (physically
 contiguous if the device memory is fresh): does the time depend on the distances between input, planes and RGB?
-usage (GPU box, repo root): python tools/placement_offsets.py"""
+usage (GPU box, repo root): python tools/placement/placement_offsets.py"""
 import os
 import sys
 
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from minivideo_amd import HotPath
 from minivideo_amd.synth import synth_packed
 

@@ -2,14 +2,14 @@
 """Measurement: do the groups found by the pairwise write probe predict the decode launch's time?  One process: classify every
 4 GB of a 230-GB allocation (mvhp_probe_pair, greedy clustering), then time the Baseline launch with its buffers at many
 positions and print the groups under each buffer next to the time.
-usage (GPU box, repo root): python tools/placement_predict.py"""
+usage (GPU box, repo root): python tools/placement/placement_predict.py"""
 import ctypes as C
 import os
 import sys
 
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from minivideo_amd import HotPath
 from minivideo_amd.hotpath import lib
 from minivideo_amd.synth import synth_packed

@@ -1,13 +1,13 @@
 #!/usr/bin/env python3
 """Measurement: which half of the memory system is every 4 GB of one large allocation in?  (mvhp_probe_pair against offset 0)
-usage (GPU box, repo root): python tools/probe_map.py [GB of the arena]"""
+usage (GPU box, repo root): python tools/placement/probe_map.py [GB of the arena]"""
 import ctypes as C
 import os
 import sys
 
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from minivideo_amd.hotpath import lib
 
 L = lib()

@@ -1,13 +1,13 @@
 #!/usr/bin/env python3
 """Measurement: pairwise mvhp_probe_pair between windows 8 GB apart in one large allocation -> which windows share a
-part of the memory system?  usage (GPU box, repo root): python tools/probe_matrix.py [window MB] [step GB]"""
+part of the memory system?  usage (GPU box, repo root): python tools/placement/probe_matrix.py [window MB] [step GB]"""
 import ctypes as C
 import os
 import sys
 
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from minivideo_amd.hotpath import lib
 
 L = lib()
