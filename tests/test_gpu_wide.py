@@ -149,6 +149,40 @@ def test_automatic_choice_by_batch_size(torch_cuda):
     torch.cuda.empty_cache()
 
 
+def test_automatic_choice_on_odd_shapes(torch_cuda):
+    """whatever pick_layout takes for pictures of one row, one column, two by two, 720p-like and portrait shapes at batch sizes on
+    both sides of every threshold: the sampled pictures (first, last, four in between) are the oracle's, and the launch reports no
+    error word"""
+    torch = torch_cuda
+    hot = HotPath(0)
+    seen = set()
+    try:
+        hot.set_layout("auto")
+        for (W, H) in [(2, 2), (20, 1), (1, 20), (30, 17), (9, 45)]:
+            for profile in ("baseline", "high"):
+                params, rec = synth_packed(W, H, 4, seed=W * 100 + H, profile=profile, density="dense")
+                ref = _oracle(params, rec, 4)
+                for n in (1, 3, 5, 68, 100, 300, 320, 321, 400, 861, 1100):
+                    d_packed = _tile(torch, rec, n)
+                    d_yuv = torch.zeros(n * params.yuv_bytes, dtype=torch.uint8, device="cuda")
+                    d_rgb = torch.zeros(n * params.rgb_bytes, dtype=torch.uint8, device="cuda")
+                    torch.cuda.synchronize()
+                    hot.recon_dev(params, d_packed.data_ptr(), n, d_yuv.data_ptr(), d_rgb.data_ptr(), None)
+                    hot.sync_check(None)
+                    seen.add(hot.last_launch()[0])
+                    yuv = d_yuv.view(n, -1)
+                    rgb = d_rgb.view(n, -1)
+                    for f in sorted({0, n - 1, n // 2, n // 3, (2 * n) // 3, max(0, n - 2)}):
+                        assert np.array_equal(yuv[f].cpu().numpy(), ref[f % 4][0].reshape(-1)), (W, H, profile, n, f, hot.last_launch())
+                        assert np.array_equal(rgb[f].cpu().numpy(), ref[f % 4][1].reshape(-1)), (W, H, profile, n, f, hot.last_launch())
+                    del d_packed, d_yuv, d_rgb
+    finally:
+        hot.close()
+    torch.cuda.empty_cache()
+    if torch.cuda.get_device_properties(0).multi_processor_count == 256:
+        assert {"pipe", "pipe1", "wide", "quad_wide", "quad"} <= seen, seen
+
+
 def test_bookkeeping_across_launches(torch_cuda):
     """one context, sixty launches: both forms in turn, batch sizes up and down (the seam buffer grows, later launches find
     tags of earlier ones in it), two streams in turn (a launch waits for the context's previous wide launch on the other
