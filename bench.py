@@ -701,7 +701,7 @@ def main():
     placement = None
     if world == 1 and args.placement_trials > 0:
         keep = (p_packed, p_yuv, p_rgb)
-        hold, ms_other = [], []
+        hold, ms_other, ms_more_ordinary = [], [], []
         other_placed = None
 
         def time_current():
@@ -725,7 +725,18 @@ def main():
                     hold += [t_yuv, t_rgb]
                     p_packed, p_yuv, p_rgb = t_packed.data_ptr(), t_yuv.data_ptr(), (t_rgb.data_ptr() if want_rgb else None)
                     ms_other.append(time_current())
-            else:        # timed on ordinary allocations: one placed set
+            else:        # timed on ordinary allocations: two more sets of ordinary output buffers (how much this launch depends on
+                #              where its buffers happen to lie, on THIS box), then one placed set
+                for _ in range(2):
+                    t_yuv = torch.empty(F * params.yuv_bytes, dtype=torch.uint8, device=dev)
+                    t_rgb = torch.empty(F * params.rgb_bytes, dtype=torch.uint8, device=dev) if want_rgb else None
+                    hold += [t_yuv, t_rgb]
+                    p_yuv, p_rgb = t_yuv.data_ptr(), (t_rgb.data_ptr() if want_rgb else None)
+                    ms_more_ordinary.append(time_current())
+                p_packed, p_yuv, p_rgb = keep
+                hold.clear()
+                t_yuv = t_rgb = None
+                torch.cuda.empty_cache()
                 from minivideo_amd import PlacedBuffers, MiniVideoError
                 sizes = [mbs_per_step * 800, F * params.yuv_bytes] + ([F * params.rgb_bytes] if want_rgb else [])
                 other_placed = PlacedBuffers(local_rank, sizes)
@@ -743,6 +754,7 @@ def main():
         placement = {"ms_per_step_timed": round(ms_recon + ms_color, 3),
                      "timed_on": "mvhp_placed_alloc" if placed else "ordinary allocations",
                      ("ms_per_step_on_ordinary_allocations" if placed else "ms_per_step_on_placed_buffers"): [None if v is None else round(v, 3) for v in ms_other],
+                     "ms_per_step_on_two_more_sets_of_ordinary_allocations": [round(v, 3) for v in ms_more_ordinary] or None,
                      "placed_set_up_s": None if other_placed is None else round(other_placed.seconds, 2),
                      "note": placement_note or "5 launches per figure; the other kind of buffers is never part of `value`"}
         hold.clear()
