@@ -214,7 +214,8 @@ MVHP_EXPORT int mvhp_set_fused_color(mvhp_ctx_t *c, int on)
 //     pipe        0.67   1.18   1.19   1.41   1.85   2.72   4.69     -      -      three luma paths one after the other)
 //     pipe1       0.60   0.60   0.63   0.93   1.50   2.74   5.31     -      -
 //     quad        3.03   5.17   5.17   5.20   5.20   5.21   5.24   5.34   5.60
-//   Up to three Baseline pictures the quarters of a wavefront hold the SAME picture (no divergence): pipe.  pipe1 has no lock
+//   ONE Baseline picture: the quarters of a wavefront hold the same picture (no divergence): pipe (0.57 against pipe1's 0.65 ms;
+//   at three pictures 0.73 against 0.65).  pipe1 has no lock
 //   step at all and its Intra4x4 chain takes ten dependent steps instead of sixteen, but needs three resident waves per ROW.
 //   720p and 2160p: profiles/r04l_crossover_{high720,base2160,high2160,high2160b}.log.  Small batches with slices / scaling
 //   matrices: pipe1 (it reconstructs them as the one-picture kernel does), larger ones wide.
@@ -238,15 +239,15 @@ static int pick_layout(const mvhp_ctx *c, const mvhp_stream_params_t *p, int n_f
         // round 4, after the wave priorities went in (profiles/r04l_crossover_*.log: 720p, 1080p and 2160p, both profiles): what
         // decides between the one-picture forms is ROW-WAVES (three waves per row have to be resident), what decides between the
         // four-picture forms is PICTURES (a round of the unbanded kernel is 4 x CUs pictures whatever their size):
-        //   Baseline  pipe (1 ... 3) | pipe1 up to 18 x CUs row-waves | pipe up to 1.25 x CUs pictures | quad_wide | quad / oct
+        //   Baseline  pipe (1 picture) | pipe1 up to 18 x CUs row-waves | pipe up to 1.15 x CUs pictures | quad_wide | quad / oct
         //   High                       pipe1 up to 40 x CUs row-waves | wide up to 1.2 x CUs pictures  | quad_wide | quad / oct
         // quad_wide against a first round of quad: 0.84 x 4 x CUs pictures at 120 macroblocks per row (720p: 0.80), 0.65 at 240
         const double qw_share = fmin(0.84, fmax(0.60, 0.84 - 0.19 * ((double)p->width_mbs - 120.0) / 120.0));
-        if (pipe_fits && !may8 && n_frames <= 3) {
+        if (pipe_fits && !may8 && n_frames <= 1) {
             layout = MVHP_LAYOUT_PIPE;
         } else if (pipe1_fits && row_waves <= (may8 ? 40.0 : 18.0) * cus) {
             layout = MVHP_LAYOUT_PIPE1;
-        } else if (pipe_fits && !may8 && n_frames <= 1.25 * cus) {
+        } else if (pipe_fits && !may8 && n_frames <= 1.15 * cus) {
             layout = MVHP_LAYOUT_PIPE;
         } else if (may8 ? (n_frames <= 1.2 * cus) : (!pipe_fits && row_waves <= 34.0 * cus)) {
             layout = MVHP_LAYOUT_WIDE;

@@ -100,9 +100,9 @@ def _tile_on_device(torch, packed, n):
 
 
 # pictures per launch -> the kernel pick_layout takes on a 256-CU MI355X for Baseline pictures (hotpath_abi.hip: three waves per
-# row of ONE picture up to 18 x CUs row-waves = 67 pictures, of four pictures up to 1.25 x CUs pictures, the plain banded form up to
+# row of ONE picture up to 18 x CUs row-waves = 67 pictures, of four pictures up to 1.15 x CUs pictures, the plain banded form up to
 # 0.84 x 4 x CUs, then one workgroup per four pictures, and per eight for whole rounds of eight per CU)
-@pytest.mark.parametrize("n,layout", [(2, "pipe"), (40, "pipe1"), (64, "pipe1"), (128, "pipe"), (512, "quad_wide"), (1024, "quad"), (2048, "oct"), (2080, "quad")])
+@pytest.mark.parametrize("n,layout", [(1, "pipe"), (2, "pipe1"), (40, "pipe1"), (64, "pipe1"), (128, "pipe"), (512, "quad_wide"), (1024, "quad"), (2048, "oct"), (2080, "quad")])
 def test_full_hd_batches_on_the_automatic_layout(torch_cuda, base1080, n, layout):
     torch = torch_cuda
     _, packed, p, ref = base1080

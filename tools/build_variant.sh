@@ -14,7 +14,9 @@ for s in $R/minivideo_amd/csrc/hip/*.hip; do
   o=$O/$(basename $s).o
   b=$(basename $s .hip)
   mkdir -p $O/temps_$b
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -Wno-unused-value "$@" -save-temps=obj -c $s -o $O/temps_$b/$b.hip.o $INC
+  X=""; case $b in recon_oct|recon_pipe) X="-Xarch_device -mllvm=-amdgpu-sched-strategy=max-ilp";; esac   # (as minivideo_amd/build.py: extra_flags)
+  [ -n "$MVHP_NO_FILE_FLAGS" ] && X=""
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -Wno-unused-value $X "$@" -save-temps=obj -c $s -o $O/temps_$b/$b.hip.o $INC
   cp $O/temps_$b/$b.hip.o $o
   # the same ISA check as the product build, on the ISA these flags produce (a variant that fails it is not a measurement)
   # (MVHP_SKIP_ISA_CHECK=1: ablations that leave the stores out contradict the checker's store count by construction;
