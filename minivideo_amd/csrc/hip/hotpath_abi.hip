@@ -295,8 +295,9 @@ static int pick_waves(const mvhp_ctx *c, const mvhp_stream_params_t *p, int n_fr
     if (layout == MVHP_LAYOUT_WIDE) return 4;   // rows per band (built for 4: the finest grain, 17 bands per 1080p picture)
     if (layout == MVHP_LAYOUT_QUAD_WIDE) {
         // rows per band, built for 4 and 8: 8-wave workgroups fit two to a CU (LDS) = 16 waves, 4-wave ones three = 12;
-        // the finer grain is the faster one at every batch size measured (512 x 1080p: 2.89 against 2.99 ms)
-        if (nw == 0) nw = 4;
+        // the finer grain is the faster one on Baseline at every batch size measured (512 x 1080p: 2.83 against 2.95 ms), the
+        // coarser one on High from ~1.5 x CUs pictures on (640 pictures: 4.13 against 4.28; profiles/r04o_qw48_*.log)
+        if (nw == 0) nw = ((p->flags & MVHP_PARAM_MAY_HAVE_8X8) && n_frames >= 1.5 * c->n_cus) ? 8 : 4;
         nw = (nw >= 8) ? 8 : 4;
         if (nw == 8 && mvhp::recon_quad_lds_bytes((int)p->width_mbs, 8) > c->max_lds) nw = 4;
         return nw;
