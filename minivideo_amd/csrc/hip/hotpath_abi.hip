@@ -285,8 +285,10 @@ static int pick_waves(const mvhp_ctx *c, const mvhp_stream_params_t *p, int n_fr
 {
     int nw = c->waves;
     if (layout == MVHP_LAYOUT_PIPE || layout == MVHP_LAYOUT_PIPE1) {
-        // rows per band (three wavefronts each), built for 1, 2 and 4
-        if (nw == 0) nw = 4;
+        // rows per band (three wavefronts each), built for 1, 2 and 4: 4 unless asked; the one-picture form at the upper end of its
+        // range (more than 30 x CUs row-waves) packs better with single rows (150 x 1080p High: 1.61 against 1.68 ms; 64: the same;
+        // 16: 0.77 against 0.63 -- profiles/r04o_pipe1_rows.log)
+        if (nw == 0) nw = (layout == MVHP_LAYOUT_PIPE1 && (double)n_frames * (double)p->height_mbs > 30.0 * c->n_cus) ? 1 : 4;
         nw = (nw >= 4) ? 4 : (nw >= 2 ? 2 : 1);
         while (nw > 1 && (layout == MVHP_LAYOUT_PIPE ? mvhp::recon_pipe_lds_bytes((int)p->width_mbs, nw)
                                                       : mvhp::recon_pipe1_lds_bytes((int)p->width_mbs, nw)) > c->max_lds) nw /= 2;
