@@ -68,6 +68,9 @@ def parse_args():
                     help="pictures of the end-to-end leg, in total over the ranks (-1: 2048 per rank, or P with --strong; 0: skip)")
     ap.add_argument("--e2e-repeats", type=int, default=3, help="timed calls of the end-to-end leg (the median is reported)")
     ap.add_argument("--e2e-batch", type=int, default=0, help="pictures per launch in the end-to-end leg (0: engine default)")
+    ap.add_argument("--output-sets", type=int, default=3,
+                    help="sets of ordinary output buffers the timed steps write in rotation (as the engine's three batch buffers per "
+                         "context are); 1 = every step into the same buffers, as rounds 1-3 did")
     ap.add_argument("--placement-trials", type=int, default=1,
                     help="N = 1 only: re-time the launch this many times on the OTHER kind of buffers (placed when the timed steps "
                          "ran on ordinary allocations, and the other way round); reported beside value, never part of it.  A placed "
@@ -627,6 +630,19 @@ def main():
         d_yuv = torch.empty(F * params.yuv_bytes, dtype=torch.uint8, device=dev)
         d_rgb = torch.empty(F * params.rgb_bytes, dtype=torch.uint8, device=dev) if want_rgb else None
         p_packed, p_yuv, p_rgb = d_packed.data_ptr(), d_yuv.data_ptr(), (d_rgb.data_ptr() if want_rgb else None)
+    # Output buffers in ROTATION (ordinary allocations only): consecutive steps write different sets, as the decode engine's
+    # three batch buffers per context are used -- and so that `value` does not hang on where ONE set of allocations happened to
+    # land in device memory (worth up to 25 % of this launch on some boxes).  --output-sets 1 = one set, as before.
+    out_sets, rot_keep = [(p_yuv, p_rgb)], []
+    if not placed:
+        out_bytes = F * (params.yuv_bytes + (params.rgb_bytes if want_rgb else 0))
+        n_sets = max(1, min(args.output_sets, int(100e9 // max(out_bytes, 1))))
+        for _ in range(n_sets - 1):
+            t_yuv = torch.empty(F * params.yuv_bytes, dtype=torch.uint8, device=dev)
+            t_rgb = torch.empty(F * params.rgb_bytes, dtype=torch.uint8, device=dev) if want_rgb else None
+            rot_keep += [t_yuv, t_rgb]
+            out_sets.append((t_yuv.data_ptr(), t_rgb.data_ptr() if want_rgb else None))
+    launch_no = [0]
     torch.cuda.synchronize(dev)   # inputs are resident before anything is launched on the bench stream
     hot = HotPath(local_rank)
     if args.waves:
@@ -639,14 +655,18 @@ def main():
     stream_t = torch.cuda.Stream(device=dev)
     sp = stream_t.cuda_stream
     assert sp != 0
-    def step(ev=None):
+    def step(ev=None, out=None):
+        if out is None:
+            out = out_sets[launch_no[0] % len(out_sets)]
+            launch_no[0] += 1
+        o_yuv, o_rgb = out
         if ev is not None:
             ev[0].record(stream_t)
-        hot.recon_stages_dev(params, p_packed, F, p_yuv, p_rgb, sp, 3 if fused else 1)
+        hot.recon_stages_dev(params, p_packed, F, o_yuv, o_rgb, sp, 3 if fused else 1)
         if ev is not None:
             ev[1].record(stream_t)
         if want_rgb and not fused:
-            hot.recon_stages_dev(params, p_packed, F, p_yuv, p_rgb, sp, 2)
+            hot.recon_stages_dev(params, p_packed, F, o_yuv, o_rgb, sp, 2)
         if ev is not None:
             ev[2].record(stream_t)
 
@@ -686,6 +706,7 @@ def main():
     # (every rank checks its own batch; the verdicts are reduced with MIN so that a mismatch on any rank fails the run)
     from oracle import loader
     ok = True
+    p_yuv, p_rgb = out_sets[(launch_no[0] - 1) % len(out_sets)]   # what the last step wrote
     for f in sorted({0, 1, 2, 3, F // 2, F - 1} & set(range(F))):
         src = f % rec.shape[0]
         ref, ref_rgb = loader.recon(params, rec[src:src + 1], 1, want_rgb=want_rgb)
@@ -704,13 +725,14 @@ def main():
         hold, ms_other, ms_more_ordinary = [], [], []
         other_placed = None
 
-        def time_current():
+        def time_current(out=None):
+            out = out if out is not None else (p_yuv, p_rgb)
             torch.cuda.synchronize(dev)
-            step()
+            step(out=out)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(stream_t)
             for _ in range(5):
-                step()
+                step(out=out)
             e1.record(stream_t)
             torch.cuda.synchronize(dev)
             return e0.elapsed_time(e1) / 5
@@ -725,16 +747,11 @@ def main():
                     hold += [t_yuv, t_rgb]
                     p_packed, p_yuv, p_rgb = t_packed.data_ptr(), t_yuv.data_ptr(), (t_rgb.data_ptr() if want_rgb else None)
                     ms_other.append(time_current())
-            else:        # timed on ordinary allocations: two more sets of ordinary output buffers (how much this launch depends on
-                #              where its buffers happen to lie, on THIS box), then one placed set
-                for _ in range(2):
-                    t_yuv = torch.empty(F * params.yuv_bytes, dtype=torch.uint8, device=dev)
-                    t_rgb = torch.empty(F * params.rgb_bytes, dtype=torch.uint8, device=dev) if want_rgb else None
-                    hold += [t_yuv, t_rgb]
-                    p_yuv, p_rgb = t_yuv.data_ptr(), (t_rgb.data_ptr() if want_rgb else None)
-                    ms_more_ordinary.append(time_current())
-                p_packed, p_yuv, p_rgb = keep
-                hold.clear()
+            else:        # timed on ordinary allocations: every set of the rotation on its own (how much this launch depends on where
+                #              its buffers happen to lie, on THIS box), then one placed set
+                for o in out_sets:
+                    ms_more_ordinary.append(time_current(o))
+                rot_keep.clear()
                 t_yuv = t_rgb = None
                 torch.cuda.empty_cache()
                 from minivideo_amd import PlacedBuffers, MiniVideoError
@@ -754,7 +771,7 @@ def main():
         placement = {"ms_per_step_timed": round(ms_recon + ms_color, 3),
                      "timed_on": "mvhp_placed_alloc" if placed else "ordinary allocations",
                      ("ms_per_step_on_ordinary_allocations" if placed else "ms_per_step_on_placed_buffers"): [None if v is None else round(v, 3) for v in ms_other],
-                     "ms_per_step_on_two_more_sets_of_ordinary_allocations": [round(v, 3) for v in ms_more_ordinary] or None,
+                     "ms_per_step_by_set_of_ordinary_allocations": [round(v, 3) for v in ms_more_ordinary] or None,
                      "placed_set_up_s": None if other_placed is None else round(other_placed.seconds, 2),
                      "note": placement_note or "5 launches per figure; the other kind of buffers is never part of `value`"}
         hold.clear()
@@ -827,7 +844,7 @@ def main():
                 "bit_exact_vs_oracle": ok,
             },
             "kernel_ms": {recon_name: ms_recon, "ycbcr_to_rgb_kernel": ms_color},
-            "buffers": buffers_info,
+            "buffers": dict(buffers_info, output_sets_in_rotation=len(out_sets)),
             "placement": placement,
             "host_frontend": None if host_rate is None else {
                 "macroblocks_per_s_one_thread": host_rate, "stream_bytes_per_picture": stream_bytes / n_distinct,
