@@ -118,7 +118,7 @@ def measured_traffic(args, fused, kernel, frames):
            ("baseline", 120, 68, 64): "frames64"}.get((args.profile, args.width_mbs, args.height_mbs, frames))
     if tag is None:
         return None, None
-    for rnd in ("r04m", "r04h", "r04c", "r03b", "r03a", "r02f", "r02e", "r02d", "r02c", "r02b", "r02a"):
+    for rnd in ("r04q", "r04m", "r04h", "r04c", "r03b", "r03a", "r02f", "r02e", "r02d", "r02c", "r02b", "r02a"):
         name = f"{rnd}_{tag}_pmc_summary.json"
         path = os.path.join(ROOT, "profiles", name)
         if os.path.exists(path):
