@@ -240,12 +240,12 @@ static int pick_layout(const mvhp_ctx *c, const mvhp_stream_params_t *p, int n_f
         // decides between the one-picture forms is ROW-WAVES (three waves per row have to be resident), what decides between the
         // four-picture forms is PICTURES (a round of the unbanded kernel is 4 x CUs pictures whatever their size):
         //   Baseline  pipe (1 picture) | pipe1 up to 18 x CUs row-waves | pipe up to 1.15 x CUs pictures | quad_wide | quad / oct
-        //   High                       pipe1 up to 40 x CUs row-waves | wide up to 1.2 x CUs pictures  | quad_wide | quad / oct
+        //   High                       pipe1 up to 46 (rows of > 160 macroblocks: 40) x CUs row-waves | wide up to 1.2 x CUs pictures | quad_wide | quad / oct
         // quad_wide against a first round of quad: 0.84 x 4 x CUs pictures at 120 macroblocks per row (720p: 0.80), 0.65 at 240
         const double qw_share = fmin(0.84, fmax(0.60, 0.84 - 0.19 * ((double)p->width_mbs - 120.0) / 120.0));
         if (pipe_fits && !may8 && n_frames <= 1) {
             layout = MVHP_LAYOUT_PIPE;
-        } else if (pipe1_fits && row_waves <= (may8 ? 40.0 : 18.0) * cus) {
+        } else if (pipe1_fits && row_waves <= (may8 ? (p->width_mbs <= 160 ? 46.0 : 40.0) : 18.0) * cus) {
             layout = MVHP_LAYOUT_PIPE1;
         } else if (pipe_fits && !may8 && n_frames <= 1.15 * cus) {
             layout = MVHP_LAYOUT_PIPE;
@@ -286,9 +286,10 @@ static int pick_waves(const mvhp_ctx *c, const mvhp_stream_params_t *p, int n_fr
     int nw = c->waves;
     if (layout == MVHP_LAYOUT_PIPE || layout == MVHP_LAYOUT_PIPE1) {
         // rows per band (three wavefronts each), built for 1, 2 and 4: 4 unless asked; the one-picture form at the upper end of its
-        // range (more than 30 x CUs row-waves) packs better with single rows (150 x 1080p High: 1.61 against 1.68 ms; 64: the same;
-        // 16: 0.77 against 0.63 -- profiles/r04o_pipe1_rows.log)
-        if (nw == 0) nw = (layout == MVHP_LAYOUT_PIPE1 && (double)n_frames * (double)p->height_mbs > 30.0 * c->n_cus) ? 1 : 4;
+        // range (more than 0.44 x CUs pictures) packs better with single rows (150 x 1080p High: 1.61 against 1.68 ms; 64: the same;
+        // 16: 0.77 against 0.63 -- profiles/r04o_pipe1_rows.log), but not on rows of 240 macroblocks, where a seam per row costs
+        // more (75 x 2160p: 3.58 against 3.29 -- profiles/r04q_crossover_pipe1_rows.log)
+        if (nw == 0) nw = (layout == MVHP_LAYOUT_PIPE1 && n_frames > 0.44 * c->n_cus && p->width_mbs <= 160) ? 1 : 4;
         nw = (nw >= 4) ? 4 : (nw >= 2 ? 2 : 1);
         while (nw > 1 && (layout == MVHP_LAYOUT_PIPE ? mvhp::recon_pipe_lds_bytes((int)p->width_mbs, nw)
                                                       : mvhp::recon_pipe1_lds_bytes((int)p->width_mbs, nw)) > c->max_lds) nw /= 2;
