@@ -239,7 +239,7 @@ static int pick_layout(const mvhp_ctx *c, const mvhp_stream_params_t *p, int n_f
         // round 4, after the wave priorities went in (profiles/r04l_crossover_*.log: 720p, 1080p and 2160p, both profiles): what
         // decides between the one-picture forms is ROW-WAVES (three waves per row have to be resident), what decides between the
         // four-picture forms is PICTURES (a round of the unbanded kernel is 4 x CUs pictures whatever their size):
-        //   Baseline  pipe (1 picture) | pipe1 up to 18 x CUs row-waves | pipe up to 1.15 x CUs pictures | quad_wide | quad / oct
+        //   Baseline  pipe (1 picture) | pipe1 up to 18 x CUs row-waves | pipe up to 1.15 x CUs pictures | quad_wide | quad / quad_wide / oct (round model below)
         //   High                       pipe1 up to 46 (rows of > 160 macroblocks: 40) x CUs row-waves | wide up to 1.2 x CUs pictures | quad_wide | quad / oct
         // quad_wide against a first round of quad: 0.84 x 4 x CUs pictures at 120 macroblocks per row (720p: 0.80), 0.65 at 240
         const double qw_share = fmin(0.84, fmax(0.60, 0.84 - 0.19 * ((double)p->width_mbs - 120.0) / 120.0));
@@ -257,15 +257,19 @@ static int pick_layout(const mvhp_ctx *c, const mvhp_stream_params_t *p, int n_f
             // A launch is a number of "rounds" of one workgroup per CU (the batch kernels fill a CU with one workgroup), in
             // units of one full round of the four-picture kernel (5.4 ms for 4 * CUs pictures of 1080p): the four-picture
             // kernel 0.77 with one workgroup on the device .. 1.0 with all CUs busy; the eight-picture kernel 1.48 .. 1.85
-            // (8 * CUs pictures).  (1024 pictures: quad 5.4 / oct 8.3 ms, 1536: 9.7 / 8.6, 2048: 10.6 / 10.0.)
+            // (8 * CUs pictures; round 4, with the priorities: 1.45 .. 1.75).  (1100 pictures: quad 8.5 / oct 7.4 ms, 2048: 8.7 / 7.9, 2560: 13.7 / 16.1.)
             auto rounds = [&](double per_round, double lo, double hi) {
                 const double full = floor(n_frames / per_round), rem = n_frames - full * per_round;
                 return full * hi + (rem > 0 ? lo + (hi - lo) * rem / per_round : 0.0);
             };
             const double t_quad = rounds(4 * cus, 0.77, 1.0);
             const bool oct_fits = mvhp::recon_oct_lds_bytes((int)p->width_mbs, 8) <= c->max_lds;   // with six waves it loses to quad
-            const double t_oct = oct_fits ? rounds(8 * cus, 1.48, 1.85) : 1e30;
-            layout = (t_oct < t_quad) ? MVHP_LAYOUT_OCT : MVHP_LAYOUT_QUAD;
+            const double t_oct = oct_fits ? rounds(8 * cus, 1.45, 1.75) : 1e30;
+            // ... and the banded four-picture form, whose time is linear in the pictures (8-row bands at these sizes): between one
+            // and two rounds it beats both (1100 x 1080p: 5.15 ms against 8.5 / 7.4; profiles/r04q_crossover_big*.log); per round
+            // 1.0 (Baseline) / 1.05 (High) at 120 macroblocks per row, 1.55 at 240
+            const double t_qw = (n_frames / (4.0 * cus)) * ((may8 ? 1.05 : 1.0) + 0.5 * fmax(0.0, ((double)p->width_mbs - 120.0) / 120.0));
+            layout = (n_frames > 4 * cus && t_qw < t_quad && t_qw < t_oct) ? MVHP_LAYOUT_QUAD_WIDE : (t_oct < t_quad) ? MVHP_LAYOUT_OCT : MVHP_LAYOUT_QUAD;
         }
     }
     // the batch kernels address a workgroup's pictures with 32-bit offsets and keep one line buffer per picture in LDS
@@ -300,7 +304,7 @@ static int pick_waves(const mvhp_ctx *c, const mvhp_stream_params_t *p, int n_fr
         // rows per band, built for 4 and 8: 8-wave workgroups fit two to a CU (LDS) = 16 waves, 4-wave ones three = 12;
         // the finer grain is the faster one on Baseline at every batch size measured (512 x 1080p: 2.83 against 2.95 ms), the
         // coarser one on High from ~1.5 x CUs pictures on (640 pictures: 4.13 against 4.28; profiles/r04o_qw48_*.log)
-        if (nw == 0) nw = ((p->flags & MVHP_PARAM_MAY_HAVE_8X8) && n_frames >= 1.5 * c->n_cus) ? 8 : 4;
+        if (nw == 0) nw = (((p->flags & MVHP_PARAM_MAY_HAVE_8X8) && n_frames >= 1.5 * c->n_cus) || n_frames > 3.4 * c->n_cus) ? 8 : 4;
         nw = (nw >= 8) ? 8 : 4;
         if (nw == 8 && mvhp::recon_quad_lds_bytes((int)p->width_mbs, 8) > c->max_lds) nw = 4;
         return nw;

@@ -7,7 +7,7 @@
 * config 5's one-GPU shares -- 512 pictures (N = 1) and 64 pictures (N = 8) of 1080p Baseline, 16 distinct pictures tiled:
   through mvhp_recon_batch_dev on the automatic layout (asserting which kernel pick_layout took) and through the engine.
 * the launch bench.py times -- 2048 full-HD pictures on the automatic layout (eight pictures per workgroup), and 2080 (a
-  ragged tail: pick_layout's round model prefers the four-picture kernel there).
+  ragged tail: pick_layout's round model prefers the banded four-picture form there).
 
 Bit-exactness is checked against oracle/recon_ref.c on sampled pictures (every distinct source picture at least once for
 the device-pointer launches)."""
@@ -101,8 +101,9 @@ def _tile_on_device(torch, packed, n):
 
 # pictures per launch -> the kernel pick_layout takes on a 256-CU MI355X for Baseline pictures (hotpath_abi.hip: three waves per
 # row of ONE picture up to 18 x CUs row-waves = 67 pictures, of four pictures up to 1.15 x CUs pictures, the plain banded form up to
-# 0.84 x 4 x CUs, then one workgroup per four pictures, and per eight for whole rounds of eight per CU)
-@pytest.mark.parametrize("n,layout", [(1, "pipe"), (2, "pipe1"), (40, "pipe1"), (64, "pipe1"), (128, "pipe"), (512, "quad_wide"), (1024, "quad"), (2048, "oct"), (2080, "quad")])
+# 0.84 x 4 x CUs, then one workgroup per four pictures up to a full round of 4 x CUs, beyond that whichever of the banded form (linear in the
+# pictures), rounds of four and rounds of eight per CU the round model makes the shortest)
+@pytest.mark.parametrize("n,layout", [(1, "pipe"), (2, "pipe1"), (40, "pipe1"), (64, "pipe1"), (128, "pipe"), (512, "quad_wide"), (1024, "quad"), (1100, "quad_wide"), (2048, "oct"), (2080, "quad_wide")])
 def test_full_hd_batches_on_the_automatic_layout(torch_cuda, base1080, n, layout):
     torch = torch_cuda
     _, packed, p, ref = base1080
