@@ -264,7 +264,7 @@ static int pick_layout(const mvhp_ctx *c, const mvhp_stream_params_t *p, int n_f
             };
             const double t_quad = rounds(4 * cus, 0.77, 1.0);
             const bool oct_fits = mvhp::recon_oct_lds_bytes((int)p->width_mbs, 8) <= c->max_lds;   // with six waves it loses to quad
-            const double t_oct = oct_fits ? rounds(8 * cus, 1.45, 1.75) : 1e30;
+            const double t_oct = oct_fits ? (may8 ? rounds(8 * cus, 1.75, 1.95) : rounds(8 * cus, 1.45, 1.75)) : 1e30;   // (High: 10.3 against 5.3 ms per round)
             // ... and the banded four-picture form, whose time is linear in the pictures (8-row bands at these sizes): between one
             // and two rounds it beats both (1100 x 1080p: 5.15 ms against 8.5 / 7.4; profiles/r04q_crossover_big*.log); per round
             // 1.0 (Baseline) / 1.05 (High) at 120 macroblocks per row, 1.55 at 240
