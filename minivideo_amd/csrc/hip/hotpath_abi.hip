@@ -239,17 +239,21 @@ static int pick_layout(const mvhp_ctx *c, const mvhp_stream_params_t *p, int n_f
         // round 4, after the wave priorities went in (profiles/r04l_crossover_*.log: 720p, 1080p and 2160p, both profiles): what
         // decides between the one-picture forms is ROW-WAVES (three waves per row have to be resident), what decides between the
         // four-picture forms is PICTURES (a round of the unbanded kernel is 4 x CUs pictures whatever their size):
-        //   Baseline  pipe (1 picture) | pipe1 up to 18 x CUs row-waves | pipe up to 1.15 x CUs pictures | quad_wide | quad / quad_wide / oct (round model below)
-        //   High                       pipe1 up to 46 (rows of > 160 macroblocks: 40) x CUs row-waves | wide up to 1.2 x CUs pictures | quad_wide | quad / oct
+        //   Baseline  pipe (1 picture) | pipe1 up to 18 x CUs row-waves | pipe up to 76 x CUs row-waves (rows of 240: 1.15 x CUs pictures) | quad_wide | round model
+        //   High                       pipe1 up to 46 (rows of > 160 macroblocks: 40) x CUs row-waves | wide up to 76 x CUs row-waves (rows of 240: 1.2 x CUs pictures) | quad_wide | round model
         // quad_wide against a first round of quad: 0.84 x 4 x CUs pictures at 120 macroblocks per row (720p: 0.80), 0.65 at 240
-        const double qw_share = fmin(0.84, fmax(0.60, 0.84 - 0.19 * ((double)p->width_mbs - 120.0) / 120.0));
+        const double wide_rows = fmax(0.0, ((double)p->width_mbs - 120.0) / 120.0);   // 0 at 1080p, 1 at 2160p
+        const double qw_share = fmin(0.84, fmax(0.60, 0.84 - (may8 ? 0.19 : 0.06) * wide_rows));
+        // four pictures per wavefront in bands against the forms below them: 76 x CUs row-waves on rows of up to 160 macroblocks
+        // (720p: 450 pictures, 1080p: 300), at most 2 x CUs pictures; on longer rows 1.15 / 1.2 x CUs pictures (r04r_grid*.log)
+        const bool below_qw = (p->width_mbs <= 160) ? (row_waves <= 76.0 * cus && n_frames <= 2.0 * cus) : (n_frames <= (may8 ? 1.2 : 1.15) * cus);
         if (pipe_fits && !may8 && n_frames <= 1) {
             layout = MVHP_LAYOUT_PIPE;
         } else if (pipe1_fits && row_waves <= (may8 ? (p->width_mbs <= 160 ? 46.0 : 40.0) : 18.0) * cus) {
             layout = MVHP_LAYOUT_PIPE1;
-        } else if (pipe_fits && !may8 && n_frames <= 1.15 * cus) {
+        } else if (pipe_fits && !may8 && below_qw) {
             layout = MVHP_LAYOUT_PIPE;
-        } else if (may8 ? (n_frames <= 1.2 * cus) : (!pipe_fits && row_waves <= 34.0 * cus)) {
+        } else if (may8 ? below_qw : (!pipe_fits && row_waves <= 34.0 * cus)) {
             layout = MVHP_LAYOUT_WIDE;
         } else if (n_frames <= qw_share * 4.0 * cus) {
             layout = MVHP_LAYOUT_QUAD_WIDE;
@@ -262,13 +266,14 @@ static int pick_layout(const mvhp_ctx *c, const mvhp_stream_params_t *p, int n_f
                 const double full = floor(n_frames / per_round), rem = n_frames - full * per_round;
                 return full * hi + (rem > 0 ? lo + (hi - lo) * rem / per_round : 0.0);
             };
-            const double t_quad = rounds(4 * cus, 0.77, 1.0);
+            // (2160p High: one 16-wave workgroup per CU, a partial round costs a whole one: 1300 pictures 40.4 ms = 2 x 20)
+            const double t_quad = rounds(4 * cus, (may8 && p->width_mbs > 160) ? 1.0 : 0.77, 1.0);
             const bool oct_fits = mvhp::recon_oct_lds_bytes((int)p->width_mbs, 8) <= c->max_lds;   // with six waves it loses to quad
-            const double t_oct = oct_fits ? (may8 ? rounds(8 * cus, 1.75, 1.95) : rounds(8 * cus, 1.45, 1.75)) : 1e30;   // (High: 10.3 against 5.3 ms per round)
+            const double t_oct = oct_fits ? (may8 ? rounds(8 * cus, 1.8, 2.0) : rounds(8 * cus, 1.45, 1.75)) : 1e30;   // (High: 10.3 against 5.3 ms per round)
             // ... and the banded four-picture form, whose time is linear in the pictures (8-row bands at these sizes): between one
             // and two rounds it beats both (1100 x 1080p: 5.15 ms against 8.5 / 7.4; profiles/r04q_crossover_big*.log); per round
-            // 1.0 (Baseline) / 1.05 (High) at 120 macroblocks per row, 1.55 at 240
-            const double t_qw = (n_frames / (4.0 * cus)) * ((may8 ? 1.05 : 1.0) + 0.5 * fmax(0.0, ((double)p->width_mbs - 120.0) / 120.0));
+            // 1.0 (Baseline) / 1.05 (High) at 120 macroblocks per row, 1.14 / 1.49 at 240
+            const double t_qw = (n_frames / (4.0 * cus)) * (may8 ? 1.05 + 0.44 * wide_rows : 1.0 + 0.14 * wide_rows);
             layout = (n_frames > 4 * cus && t_qw < t_quad && t_qw < t_oct) ? MVHP_LAYOUT_QUAD_WIDE : (t_oct < t_quad) ? MVHP_LAYOUT_OCT : MVHP_LAYOUT_QUAD;
         }
     }
@@ -304,7 +309,7 @@ static int pick_waves(const mvhp_ctx *c, const mvhp_stream_params_t *p, int n_fr
         // rows per band, built for 4 and 8: 8-wave workgroups fit two to a CU (LDS) = 16 waves, 4-wave ones three = 12;
         // the finer grain is the faster one on Baseline at every batch size measured (512 x 1080p: 2.83 against 2.95 ms), the
         // coarser one on High from ~1.5 x CUs pictures on (640 pictures: 4.13 against 4.28; profiles/r04o_qw48_*.log)
-        if (nw == 0) nw = (((p->flags & MVHP_PARAM_MAY_HAVE_8X8) && n_frames >= 1.5 * c->n_cus) || n_frames > 3.4 * c->n_cus) ? 8 : 4;
+        if (nw == 0) nw = (p->width_mbs <= 160 && (((p->flags & MVHP_PARAM_MAY_HAVE_8X8) && n_frames >= 1.5 * c->n_cus) || n_frames > 3.4 * c->n_cus)) ? 8 : 4;   // (rows of 240: 4 everywhere)
         nw = (nw >= 8) ? 8 : 4;
         if (nw == 8 && mvhp::recon_quad_lds_bytes((int)p->width_mbs, 8) > c->max_lds) nw = 4;
         return nw;

@@ -116,10 +116,10 @@ def test_band_boundaries(layout, W, H):
 
 def test_automatic_choice_by_batch_size(torch_cuda):
     """pick_layout on a 256-CU device.  Baseline: one picture four times per wavefront with three waves
-    per row; up to 18 x CUs row-waves (pictures x rows) one picture per wavefront with three waves per row; up to 1.15 x CUs
-    PICTURES four per wavefront again; up to 0.84 x 4 x CUs pictures four pictures in bands; then one workgroup per group.
+    per row; up to 18 x CUs row-waves (pictures x rows) one picture per wavefront with three waves per row; up to 76 x CUs
+    row-waves (and 2 x CUs pictures) four per wavefront again; up to 0.84 x 4 x CUs pictures four pictures in bands; then one workgroup per group.
     Batches that may hold Intra8x8 macroblocks: up to 46 x CUs row-waves one picture per wavefront with three waves per row, up
-    to 1.2 x CUs pictures one picture in bands, then as Baseline."""
+    to 76 x CUs row-waves one picture in bands, then as Baseline."""
     torch = torch_cuda
     if torch.cuda.get_device_properties(0).multi_processor_count != 256:
         pytest.skip("thresholds are stated for 256 CUs")
@@ -128,10 +128,10 @@ def test_automatic_choice_by_batch_size(torch_cuda):
         hot.set_layout("auto")
         for (W, H, n, flags, want) in [(20, 17, 1, 0, "pipe"), (20, 17, 2, 0, "pipe1"), (20, 17, 3, 1, "pipe1"), (20, 17, 4, 1, "pipe1"), (20, 17, 4, 0, "pipe1"),
                                        (20, 17, 271, 0, "pipe1"), (20, 17, 272, 0, "pipe"),
-                                       (20, 17, 294, 0, "pipe"), (20, 17, 295, 0, "quad_wide"), (20, 68, 67, 0, "pipe1"), (20, 68, 68, 0, "pipe"),
-                                       (20, 68, 294, 0, "pipe"),
-                                       (20, 68, 295, 0, "quad_wide"), (20, 68, 173, 1, "pipe1"), (20, 68, 174, 1, "wide"),
-                                       (20, 68, 307, 1, "wide"), (20, 68, 308, 1, "quad_wide"),
+                                       (20, 17, 512, 0, "pipe"), (20, 17, 513, 0, "quad_wide"), (20, 68, 67, 0, "pipe1"), (20, 68, 68, 0, "pipe"),
+                                       (20, 68, 286, 0, "pipe"),
+                                       (20, 68, 287, 0, "quad_wide"), (20, 68, 173, 1, "pipe1"), (20, 68, 174, 1, "wide"),
+                                       (20, 68, 286, 1, "wide"), (20, 68, 287, 1, "quad_wide"),
                                        (6, 68, 860, 0, "quad_wide"), (6, 68, 861, 0, "quad")]:
             params, rec = synth_packed(W, H, 4, seed=7, profile="baseline", density="light")
             params.flags = flags   # bit 0: MVHP_PARAM_MAY_HAVE_8X8 (a hint for this choice only)

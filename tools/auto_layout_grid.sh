@@ -1,13 +1,16 @@
 # Every kernel form against the automatic choice on a dense grid of batch sizes (1080p, both profiles): flags sizes at which
-# pick_layout is more than 4 % off the best form.  usage (GPU box, repo root): bash tools/auto_layout_grid.sh
-S=1,2,3,4,8,16,32,48,64,68,80,96,113,128,150,173,200,256,294,308,350,400,512,640,768,860,900,1024,1100,1400,1700,1800,2048,2300,2560,3072,4096
+# pick_layout is more than 4 % off the best form.  usage (GPU box, repo root): bash tools/auto_layout_grid.sh [WxH in macroblocks] [sizes] [tag]
+MBS=${1:-120x68}
+S=${2:-1,2,3,4,8,16,32,48,64,68,80,96,113,128,150,173,200,256,294,308,350,400,512,640,768,860,900,1024,1100,1400,1700,1800,2048,2300,2560,3072,4096}
+TAG=${3:-r04r_grid}
 for prof in baseline high; do
-  timeout -k 10 500 python tools/layout_crossover.py --profile $prof --sizes $S --layouts pipe,pipe1,pipe1:1,wide,quad_wide:4,quad_wide:8,quad,oct,auto 2>&1 | grep -v amdgpu > gpurun_out/r04r_grid_$prof.log
+  timeout -k 10 500 python tools/layout_crossover.py --profile $prof --mbs $MBS --sizes $S --layouts pipe,pipe1,pipe1:1,wide,quad_wide:4,quad_wide:8,quad,oct,auto 2>&1 | grep -v amdgpu > gpurun_out/${TAG}_$prof.log
 done
-python - <<'PY'
+TAG=$TAG python - <<'PY'
 import re
 for prof in ("baseline","high"):
-    L=open(f"gpurun_out/r04r_grid_{prof}.log").read().split("\n")
+    import os
+    L=open(f"gpurun_out/{os.environ.get('TAG','r04r_grid')}_{prof}.log").read().split("\n")
     names=L[0].split()[1:10]
     print(prof)
     for l in L[1:]:
